@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE (trinhvg/MoMA) on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box has no reference and only ever
+reads the committed .npz files):
+
+    python tests/golden/make_golden.py
+
+What is captured:
+  G1 attention   MoMA/criterion_moco_att.py:141-167   y and, for the atts_q role, dx/dW*/db*
+  G2 queue       MoMA/mem_moco.py:69-100              index/out_ids/memory/logits/labels traces
+  G3 ema         learning/contrast_trainer.py:207-211 momentum_update on a ragged tensor list
+  G4 infonce     MoCo.forward + nn.CrossEntropyLoss   loss, dq, top-1 accuracy
+  G5 step trace  helper/loops_moma.py:221-373         10 steps of train_distill_moma (resnet8 pair)
+
+Only arrays (inputs / expected outputs) are written; no reference source text is stored.
+Shims needed to import the reference on a CPU-only box: a stub
+`tensorboard_logger` module, `.cuda()` patched to identity, gloo world_size=1 process group.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("MOMA_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _shims():
+    sys.path.insert(0, REF)
+    sys.modules.setdefault("tensorboard_logger", types.ModuleType("tensorboard_logger"))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+
+def g1_attention():
+    from MoMA.criterion_moco_att import Attention
+    out = {}
+    cases = [(8, 64, 4), (16, 128, 4), (32, 96, 8), (5, 32, 4), (1, 32, 4)]
+    for ci, (n, d, h) in enumerate(cases):
+        torch.manual_seed(1000 + ci)
+        att = Attention(d, num_heads=h, qkv_bias=True)
+        x = torch.randn(n, d, requires_grad=True)
+        dy = torch.randn(n, d)
+        y = att(x)
+        (y * dy).sum().backward()
+        p = f"c{ci}_"
+        out[p + "shape"] = np.array([n, d, h], dtype=np.int64)
+        out[p + "x"] = x.detach().numpy()
+        out[p + "dy"] = dy.numpy()
+        out[p + "w_qkv"] = att.qkv.weight.detach().numpy()
+        out[p + "b_qkv"] = att.qkv.bias.detach().numpy()
+        out[p + "w_proj"] = att.proj.weight.detach().numpy()
+        out[p + "b_proj"] = att.proj.bias.detach().numpy()
+        out[p + "y"] = y.detach().numpy()
+        out[p + "dx"] = x.grad.numpy()
+        out[p + "d_wqkv"] = att.qkv.weight.grad.numpy()
+        out[p + "d_bqkv"] = att.qkv.bias.grad.numpy()
+        out[p + "d_wproj"] = att.proj.weight.grad.numpy()
+        out[p + "d_bproj"] = att.proj.bias.grad.numpy()
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g1_attention.npz"), **out)
+
+
+def g2_queue():
+    from MoMA.mem_moco import MoCo
+    out = {}
+    # (K, d, B, n_all, steps): K not divisible by n, n == B, n == 2B (all_k larger than k), n > K wrap
+    cases = [(40, 8, 16, 16, 7), (64, 16, 8, 8, 10), (50, 8, 6, 12, 9), (10, 4, 4, 12, 3), (33, 8, 5, 5, 15)]
+    for ci, (K, d, B, n, steps) in enumerate(cases):
+        torch.manual_seed(2000 + ci)
+        mem = MoCo(d, K, 0.15)
+        p = f"c{ci}_"
+        out[p + "cfg"] = np.array([K, d, B, n, steps], dtype=np.int64)
+        out[p + "memory0"] = mem.memory.numpy().copy()
+        idx_trace, mem_trace, logit_trace, q_trace, k_trace, allk_trace, label_trace = [], [], [], [], [], [], []
+        for s in range(steps):
+            q = torch.randn(B, d)
+            k = torch.randn(B, d)
+            all_k = k if n == B else torch.randn(n, d)
+            logits, labels = mem(q, k, all_k=None if n == B else all_k)
+            idx_trace.append(mem.index)
+            mem_trace.append(mem.memory.numpy().copy())
+            logit_trace.append(logits.numpy().copy())
+            label_trace.append(labels.numpy().copy())
+            q_trace.append(q.numpy()); k_trace.append(k.numpy()); allk_trace.append(all_k.numpy())
+        out[p + "index"] = np.array(idx_trace, dtype=np.int64)
+        out[p + "memory"] = np.stack(mem_trace)
+        out[p + "logits"] = np.stack(logit_trace)
+        out[p + "labels"] = np.stack(label_trace)
+        out[p + "q"] = np.stack(q_trace)
+        out[p + "k"] = np.stack(k_trace)
+        out[p + "all_k"] = np.stack(allk_trace)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g2_queue.npz"), **out)
+
+
+def g3_ema():
+    from learning.contrast_trainer import ContrastTrainer
+
+    class Rag(nn.Module):
+        def __init__(self):
+            super().__init__()
+            shapes = [(1,), (3,), (7, 5), (64,), (33, 17), (4, 3, 3, 3), (1025,), (2, 2)]
+            self.ps = nn.ParameterList([nn.Parameter(torch.randn(*s)) for s in shapes])
+
+    out = {}
+    for ci, m in enumerate([0.999, 0.0, 0.5, 0.9]):
+        torch.manual_seed(3000 + ci)
+        a, b = Rag(), Rag()
+        p = f"c{ci}_"
+        out[p + "m"] = np.array(m, dtype=np.float64)
+        for i, (pa, pb) in enumerate(zip(a.parameters(), b.parameters())):
+            out[p + f"p{i}"] = pa.detach().numpy().copy()
+            out[p + f"e{i}"] = pb.detach().numpy().copy()
+        for _ in range(3):   # three successive updates
+            ContrastTrainer.momentum_update(a, b, m)
+        for i, pb in enumerate(b.parameters()):
+            out[p + f"r{i}"] = pb.detach().numpy().copy()
+        out[p + "n"] = np.array(len(list(a.parameters())))
+    out["n_cases"] = np.array(4)
+    np.savez_compressed(os.path.join(OUT, "g3_ema.npz"), **out)
+
+
+def g4_infonce():
+    from MoMA.mem_moco import MoCo
+    from learning.contrast_trainer import ContrastTrainer
+    out = {}
+    cases = [(8, 64, 40), (8, 256, 64), (3, 32, 17), (16, 128, 300)]
+    for ci, (B, d, K) in enumerate(cases):
+        torch.manual_seed(4000 + ci)
+        mem = MoCo(d, K, 0.15)
+        # structured, non-degenerate inputs: correlated q/k, a few rows aligned with queue entries
+        base = torch.randn(B, d)
+        q = torch.nn.functional.normalize(base + 0.3 * torch.randn(B, d), dim=1)
+        k = torch.nn.functional.normalize(base + 0.3 * torch.randn(B, d), dim=1)
+        q = q.clone()
+        q[1] = torch.nn.functional.normalize(mem.memory[3] + 0.05 * torch.randn(d), dim=0)  # top-1 miss
+        q.requires_grad_(True)
+        mem0 = mem.memory.numpy().copy()
+        logits, labels = mem(q, k)
+        crit = nn.CrossEntropyLoss()
+        losses, accs = ContrastTrainer._compute_loss_accuracy(logits=[logits], target=labels, criterion=crit)
+        losses[0].backward()
+        p = f"c{ci}_"
+        out[p + "cfg"] = np.array([B, d, K], dtype=np.int64)
+        out[p + "memory0"] = mem0
+        out[p + "q"] = q.detach().numpy(); out[p + "k"] = k.numpy()
+        out[p + "logits"] = logits.detach().numpy()
+        out[p + "loss"] = np.array(losses[0].item(), dtype=np.float64)
+        out[p + "acc"] = np.array(accs[0].item(), dtype=np.float64)
+        out[p + "dq"] = q.grad.numpy()
+        out[p + "memory1"] = mem.memory.numpy().copy()
+        out[p + "index1"] = np.array(mem.index)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g4_infonce.npz"), **out)
+
+
+def g5_step_trace():
+    """10 steps of the reference loop, resnet8 student/teacher (same arch so the zip-EMA is defined,
+    SURVEY Q4), B=8, 32x32, n_cls=100, K=64, head in {None, mlp}, -c 1 -d 1 -b 1, attn=self."""
+    import argparse
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import helper.loops_moma as L
+    from models.resnet import resnet8
+    from MoMA.mem_moco import build_mem
+    from MoMA.criterion_moco_att import CMO
+    from learning.contrast_trainer import ContrastTrainer
+    from distiller_zoo import DistillKL
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+    out = {}
+    for ci, (head, feat_dim) in enumerate([("None", 64), ("mlp", 32)]):
+        opt = argparse.Namespace(
+            distill="moma", head=head, feat_dim=feat_dim, attn="self", mem="MoCo", nce_k=64, nce_t=0.15,
+            alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=None, multiprocessing_distributed=True,
+            print_freq=1000, batch_size=8, local_rank=0, node_rank=0, ngpus_per_node=1, rank=0, world_size=1)
+        torch.manual_seed(5000 + ci)
+        model_s = resnet8(num_classes=100)
+        model_t = resnet8(num_classes=100)
+        opt.s_dim = opt.t_dim = 64
+        if head == "None":
+            opt.feat_dim = opt.s_dim
+        contrast = build_mem(opt)
+        criterion_kd = CMO(opt)
+        trainer = ContrastTrainer(opt)
+        trainer.local_group = dist.new_group([0])
+        module_list = nn.ModuleList([model_s])
+        trainable = nn.ModuleList([model_s])
+        trainable.append(criterion_kd.atts_q)
+        trainable.append(criterion_kd.atts_k)
+        trainable.append(criterion_kd.atts_queue)
+        if head == "mlp":
+            trainable.append(criterion_kd.embed_s)
+        optimizer = torch.optim.SGD(trainable.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        p = f"c{ci}_"
+        for name, t in model_s.state_dict().items():
+            out[p + "s." + name] = t.numpy().copy()
+        for name, t in model_t.state_dict().items():
+            out[p + "t." + name] = t.numpy().copy()
+        for name, t in criterion_kd.state_dict().items():
+            out[p + "kd." + name] = t.numpy().copy()
+        out[p + "memory0"] = contrast.memory.numpy().copy()
+        ddp_s = DDP(model_s)
+        mods = nn.ModuleList([ddp_s, model_t])
+        crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(opt.kd_T), criterion_kd])
+
+        steps_per_epoch, epochs = 5, 2
+        g = torch.Generator().manual_seed(777 + ci)
+        images = torch.randn(steps_per_epoch * epochs, 8, 3, 32, 32, generator=g)
+        labels = torch.randint(0, 100, (steps_per_epoch * epochs, 8), generator=g)
+        out[p + "data_seed"] = np.array(777 + ci)
+        out[p + "images_sum"] = np.array(images.double().sum().item())
+        out[p + "labels"] = labels.numpy()
+
+        rec = {"loss": [], "acc": [], "index": [], "memsum": []}
+
+        class RecMeter(L.AverageMeter):
+            pass
+
+        # record per-step loss / acc through the meters the loop updates (helper/loops_moma.py:351-356)
+        orig_update = L.AverageMeter.update
+        calls = {"n": 0}
+
+        def upd(self, val, n=1):
+            k = calls["n"] % 3
+            if k == 0:
+                rec["loss"].append(val)
+            elif k == 1:
+                rec["acc"].append(val)
+            calls["n"] += 1
+            return orig_update(self, val, n)
+
+        L.AverageMeter.update = upd
+        torch.manual_seed(9000 + ci)      # RNG stream for the per-step randperm of _shuffle_bn
+        out[p + "loop_seed"] = np.array(9000 + ci)
+        try:
+            for ep in range(epochs):
+                loader = [(images[ep * steps_per_epoch + i], labels[ep * steps_per_epoch + i])
+                          for i in range(steps_per_epoch)]
+
+                class Rec(list):
+                    pass
+                # run one batch at a time inside an epoch by wrapping the loader to record queue state
+                def gen():
+                    for it in loader:
+                        yield it
+                        rec["index"].append(contrast.index)
+                        rec["memsum"].append(contrast.memory.double().sum().item())
+
+                class LL:
+                    def __len__(self): return steps_per_epoch
+                    def __iter__(self): return gen()
+                L.train_distill_moma(ep + 1, LL(), mods, crits, trainer, contrast, optimizer, opt)
+        finally:
+            L.AverageMeter.update = orig_update
+        out[p + "loss"] = np.array(rec["loss"], dtype=np.float64)
+        out[p + "acc"] = np.array(rec["acc"], dtype=np.float64)
+        out[p + "index"] = np.array(rec["index"], dtype=np.int64)
+        out[p + "memsum"] = np.array(rec["memsum"], dtype=np.float64)
+        out[p + "memory_final"] = contrast.memory.numpy().copy()
+        out[p + "atts_k_grad_none"] = np.array(all(q.grad is None for q in criterion_kd.atts_k.parameters()))
+        out[p + "atts_queue_grad_none"] = np.array(all(q.grad is None for q in criterion_kd.atts_queue.parameters()))
+        for name, t in model_s.state_dict().items():
+            if name.endswith("fc.weight") or name.endswith("conv1.weight"):
+                out[p + "s_final." + name] = t.numpy().copy()
+        for name, t in model_t.state_dict().items():
+            if name.endswith("fc.weight"):
+                out[p + "t_final." + name] = t.numpy().copy()
+        out[p + "kd_final.atts_q.proj.weight"] = criterion_kd.atts_q.proj.weight.detach().numpy().copy()
+        out[p + "kd_final.atts_k.proj.weight"] = criterion_kd.atts_k.proj.weight.detach().numpy().copy()
+        out[p + "head"] = np.array(head)
+    out["n_cases"] = np.array(2)
+    np.savez_compressed(os.path.join(OUT, "g5_step_trace.npz"), **out)
+
+
+if __name__ == "__main__":
+    _shims()
+    torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    if "g1" in which: g1_attention()
+    if "g2" in which: g2_queue()
+    if "g3" in which: g3_ema()
+    if "g4" in which: g4_infonce()
+    if "g5" in which: g5_step_trace()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
