@@ -1,0 +1,125 @@
+/*
+ * moma_hip.h -- C ABI of libmoma_hip.so: the MI355X (gfx950) kernels behind MoMA's
+ * contrastive-distillation training step.
+ *
+ * The reference (trinhvg/MoMA) is pure Python on PyTorch and has no native interface of its own, so
+ * every entry point below replaces a *chain of ATen ops* at a reference call site; the call site is
+ * cited per function (paths relative to the reference root).  A maintainer binds these with ctypes
+ * (see INTEGRATION.md); moma_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (torch tensors' data_ptr()); nothing is
+ *     retained past the call; the library allocates no device memory: workspaces are caller-provided
+ *     and sized by the *_workspace_bytes() queries;
+ *   - every launch function takes the hipStream_t to enqueue on (as void*), is asynchronous on it and
+ *     performs no host synchronisation (safe under hipGraph capture);
+ *   - return value: 0 = ok, <0 = argument check failed (MOMA_E_*), >0 = hipError_t of a failed launch;
+ *     nothing throws; no global mutable state (re-entrant; one host thread per process/GPU);
+ *   - matrices are row-major and dense unless a leading dimension is given;
+ *   - `prec`   : arithmetic of the contractions. MOMA_PREC_F32 = f32-input MFMA (exact fp32 fma chain,
+ *                the reference's arithmetic), MOMA_PREC_BF16 = bf16-input MFMA with fp32 accumulate;
+ *   - `qdtype` : storage type of the K x d feature queue (MOMA_DT_F32 = reference storage,
+ *                MOMA_DT_BF16 = 2-byte rows).
+ */
+#ifndef MOMA_HIP_H
+#define MOMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOMA_ABI_VERSION 1
+
+enum { MOMA_PREC_F32 = 0, MOMA_PREC_BF16 = 1 };
+enum { MOMA_DT_F32 = 0, MOMA_DT_BF16 = 1 };
+
+enum {
+    MOMA_OK = 0,
+    MOMA_E_NULL = -1,      /* a required pointer is NULL                        */
+    MOMA_E_SHAPE = -2,     /* a dimension is <= 0 or inconsistent               */
+    MOMA_E_DTYPE = -3,     /* unknown prec / qdtype                             */
+    MOMA_E_ALIGN = -4,     /* pointer not aligned to its element size           */
+    MOMA_E_WORKSPACE = -5, /* workspace too small                               */
+    MOMA_E_UNSUPPORTED = -6
+};
+
+typedef void* moma_stream_t; /* hipStream_t */
+
+/* ABI version (== MOMA_ABI_VERSION of the header the library was built from). */
+int moma_version(void);
+/* Human-readable text for a return code of this library (static storage). */
+const char* moma_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  multi-tensor EMA -- replaces ContrastTrainer.momentum_update
+ *     (learning/contrast_trainer.py:207-211: per-tensor p2.mul_(m).add_(p1, alpha=1-m)).
+ *     One launch for the whole parameter list:  ema = fma(fl32(1-m), p, fl32(ema*fl32(m))).
+ *     `table` is a device array of n_tensors records {int64 ema_ptr, int64 p_ptr, int64 numel,
+ *     int64 first_block}; first_block = exclusive prefix sum of ceil(numel / MOMA_EMA_BLOCK_ELEMS);
+ *     total_blocks = that sum.  The table is built once per model pair by the host.
+ * ------------------------------------------------------------------------------------------- */
+#define MOMA_EMA_BLOCK_ELEMS 4096
+int moma_ema_multi(const int64_t* table, int n_tensors, int64_t total_blocks,
+                   float m, float one_minus_m, moma_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  ring-buffer enqueue -- replaces BaseMoCo._update_memory (MoMA/mem_moco.py:17-27:
+ *     arange+index -> fmod(K) -> index_copy_).   queue[(index+i) mod K, :] = rows[i, :], i in [0,n).
+ *     n > K (duplicate slots) is last-writer-wins like a serial index_copy_.  The pointer update
+ *     index = (index+n) mod K (MoMA/mem_moco.py:14-15) stays a host integer in the caller.
+ *     rows are fp32 [n,d]; queue is [K,d] in `qdtype` (bf16 rows are rounded to nearest even).
+ * ------------------------------------------------------------------------------------------- */
+int moma_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d,
+                 int qdtype, moma_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  InfoNCE over the queue.
+ *
+ * moma_infonce_logits -- replaces BaseMoCo._compute_logit (MoMA/mem_moco.py:29-49):
+ *     out[b,0] = <q_b,k_b>*inv_T ; out[b,1+j] = <queue_j,q_b>*inv_T ; out is [B,K+1] fp32 contiguous.
+ * moma_infonce_logits_bwd -- the autograd backward of the above w.r.t. q:
+ *     dq[b,:] = (dlogits[b,0]*k_b + sum_j dlogits[b,1+j]*queue_j) * inv_T          (dq is [B,d] fp32)
+ * moma_infonce_fused -- replaces the whole chain MoCo.forward (MoMA/mem_moco.py:77-100, minus the
+ *     enqueue) + nn.CrossEntropyLoss(logits, 0) + top-1 accuracy (helper/loops_moma.py:322,331-335,
+ *     learning/contrast_trainer.py:189-205) and its backward, in one pass over the queue:
+ *       lse[b]       = logsumexp_j out[b,j]
+ *       loss_rows[b] = lse[b] - out[b,0]                  (loss_kd = mean_b loss_rows[b])
+ *       top1[b]      = 1 if out[b,0] >= max_j out[b,j] else 0
+ *       dq[b,:]      = d(sum_b loss_rows)/dq_b = ((p_b0-1)*k_b + sum_j p_bj*queue_j)*inv_T
+ *     dq may be NULL (forward only).  workspace: moma_infonce_fused_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+int moma_infonce_logits(const float* q, const float* k, const void* queue, float* out,
+                        int B, int d, int K, float inv_T, int qdtype, int prec, moma_stream_t stream);
+int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* queue, float* dq,
+                            int B, int d, int K, float inv_T, int qdtype, int prec,
+                            moma_stream_t stream);
+size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec);
+int moma_infonce_fused(const float* q, const float* k, const void* queue, int B, int d, int K,
+                       float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
+                       void* workspace, size_t workspace_bytes, int qdtype, int prec,
+                       moma_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  batch-token multi-head attention -- replaces Attention.forward
+ *     (MoMA/criterion_moco_att.py:153-167) and its autograd backward.
+ *     x [N,d] -> qkv = x Wqkv^T + bqkv -> per head softmax(q k^T * hd^-1/2) v -> y = a Wproj^T + bproj.
+ *     fwd keeps for backward (caller-owned): qkv [N,3d], probs [H,N,N], attn_out [N,d].
+ *     bwd writes dx [N,d], dw_qkv [3d,d], db_qkv [3d], dw_proj [d,d], db_proj [d]; any of the five may
+ *     be NULL to skip it.  bwd workspace: moma_mha_bwd_workspace_bytes().
+ * ------------------------------------------------------------------------------------------- */
+int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj,
+                 const float* b_proj, float* y, float* qkv, float* probs, float* attn_out,
+                 int N, int d, int H, int prec, moma_stream_t stream);
+size_t moma_mha_bwd_workspace_bytes(int N, int d, int H);
+int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv,
+                 const float* probs, const float* attn_out, const float* dy, float* dx,
+                 float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj, void* workspace,
+                 size_t workspace_bytes, int N, int d, int H, int prec, moma_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOMA_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libmoma_hip.so (the C ABI declared in include/moma_hip.h).
+
+This is the binding a maintainer of the reference would add.  There is no fallback:
+if the shared library is missing or a symbol is absent, importing a kernel raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MOMA_HIP_LIB", os.path.join(_HERE, "lib", "libmoma_hip.so"))
+
+PREC_F32, PREC_BF16 = 0, 1
+DT_F32, DT_BF16 = 0, 1
+ABI_VERSION = 1
+EMA_BLOCK_ELEMS = 4096
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+_z = C.c_size_t
+
+# symbol -> (restype, argtypes); must list every function of include/moma_hip.h
+SIGNATURES = {
+    "moma_version": (_i, []),
+    "moma_error_string": (C.c_char_p, [_i]),
+    "moma_ema_multi": (_i, [_p, _i, _l, _f, _f, _p]),
+    "moma_enqueue": (_i, [_p, _p, _i, _l, _i, _i, _i, _p]),
+    "moma_infonce_logits": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
+    "moma_infonce_logits_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
+    "moma_infonce_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
+    "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class MomaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MomaHipError(
+            f"libmoma_hip.so not found at {LIB_PATH}: build it with `python -m moma_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the MoMA hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MomaHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.moma_version()
+    if v != ABI_VERSION:
+        raise MomaHipError(f"libmoma_hip ABI version {v} != binding version {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().moma_error_string(rc)
+        raise MomaHipError(f"{what} failed: rc={rc} ({msg.decode() if msg else '?'})")

@@ -1,0 +1,214 @@
+// extern "C" entry points of libmoma_hip.so (see include/moma_hip.h for the contract of each).
+#include "common.hpp"
+
+using namespace moma;
+
+namespace {
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? MOMA_OK : (int)e; }
+inline bool bad_prec(int p) { return p != MOMA_PREC_F32 && p != MOMA_PREC_BF16; }
+inline bool bad_dt(int t) { return t != MOMA_DT_F32 && t != MOMA_DT_BF16; }
+inline bool misaligned(const void* p, size_t a) { return ((uintptr_t)p % a) != 0; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define MOMA_TRY(expr)                         \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return (int)_e;  \
+    } while (0)
+
+GemmArgs gemm(const float* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int tA,
+              int tB, float alpha, int prec) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.strideA = g.strideB = g.strideC = 0; g.batch = 1;
+    g.transA = tA; g.transB = tB; g.alpha = alpha; g.splitk = 1; g.atomic = 0;
+    g.b_dtype = MOMA_DT_F32; g.prec = prec;
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
+int moma_version(void) { return MOMA_ABI_VERSION; }
+
+const char* moma_error_string(int code) {
+    switch (code) {
+        case MOMA_OK: return "ok";
+        case MOMA_E_NULL: return "moma: required pointer is NULL";
+        case MOMA_E_SHAPE: return "moma: bad or inconsistent dimension";
+        case MOMA_E_DTYPE: return "moma: unknown precision / queue dtype";
+        case MOMA_E_ALIGN: return "moma: pointer not aligned to its element size";
+        case MOMA_E_WORKSPACE: return "moma: workspace too small";
+        case MOMA_E_UNSUPPORTED: return "moma: unsupported configuration";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "moma: unknown error";
+    }
+}
+
+int moma_ema_multi(const int64_t* table, int n_tensors, int64_t total_blocks, float m, float one_minus_m,
+                   moma_stream_t stream) {
+    if (n_tensors == 0) return MOMA_OK;
+    if (!table) return MOMA_E_NULL;
+    if (n_tensors < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return MOMA_E_SHAPE;
+    return hip_rc(launch_ema(table, n_tensors, total_blocks, m, one_minus_m, (hipStream_t)stream));
+}
+
+int moma_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d, int qdtype,
+                 moma_stream_t stream) {
+    if (n == 0) return MOMA_OK;
+    if (!queue || !rows) return MOMA_E_NULL;
+    if (n < 0 || K <= 0 || d <= 0 || index < 0 || index >= K) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype)) return MOMA_E_DTYPE;
+    if (misaligned(rows, 4) || misaligned(queue, qdtype == MOMA_DT_BF16 ? 2 : 4)) return MOMA_E_ALIGN;
+    return hip_rc(launch_enqueue(queue, rows, n, index, K, d, qdtype, (hipStream_t)stream));
+}
+
+int moma_infonce_logits(const float* q, const float* k, const void* queue, float* out, int B, int d, int K,
+                        float inv_T, int qdtype, int prec, moma_stream_t stream) {
+    if (!q || !k || !queue || !out) return MOMA_E_NULL;
+    if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long ld = (long)K + 1;
+    MOMA_TRY(launch_pos_logit(q, k, out, ld, B, d, inv_T, st));
+    GemmArgs g = gemm(q, queue, out + 1, B, K, d, d, d, ld, 0, 0, inv_T, prec);   // neg = q . queue^T
+    g.b_dtype = qdtype;
+    return hip_rc(launch_gemm(g, st));
+}
+
+int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* queue, float* dq, int B, int d,
+                            int K, float inv_T, int qdtype, int prec, moma_stream_t stream) {
+    if (!dlogits || !k || !queue || !dq) return MOMA_E_NULL;
+    if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long ld = (long)K + 1;
+    MOMA_TRY(launch_pos_grad_init(dlogits, ld, k, dq, B, d, inv_T, st));
+    // dq += dlogits[:,1:] . queue   (contraction over K, split and combined with fp32 atomics)
+    GemmArgs g = gemm(dlogits + 1, queue, dq, B, d, K, ld, d, d, 0, 1, inv_T, prec);
+    g.b_dtype = qdtype;
+    const int tiles = ((B + 63) / 64) * ((d + 63) / 64);
+    int splitk = (1024 + tiles - 1) / tiles;
+    const int ktiles = (K + 31) / 32;
+    if (splitk > ktiles) splitk = ktiles;
+    if (splitk < 1) splitk = 1;
+    g.splitk = splitk;
+    g.atomic = 1;
+    return hip_rc(launch_gemm(g, st));
+}
+
+size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec) {
+    if (B <= 0 || d <= 0 || K <= 0) return 0;
+    if (infonce_flash_supported(B, d, K, qdtype, prec)) return infonce_flash_workspace_bytes(B, d, K);
+    return align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256);
+}
+
+int moma_infonce_fused(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
+                       float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                       size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream) {
+    if (!q || !k || !queue || !loss_rows || !lse || !top1 || !workspace) return MOMA_E_NULL;
+    if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
+    if (workspace_bytes < moma_infonce_fused_workspace_bytes(B, d, K, qdtype, prec)) return MOMA_E_WORKSPACE;
+    if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (infonce_flash_supported(B, d, K, qdtype, prec))
+        return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st));
+    // staged path (any shape, exact fp32 available): logits -> row reduction -> gradient product
+    float* logits = (float*)workspace;
+    int rc = moma_infonce_logits(q, k, queue, logits, B, d, K, inv_T, qdtype, prec, stream);
+    if (rc != MOMA_OK) return rc;
+    MOMA_TRY(launch_infonce_rows(logits, B, K + 1, loss_rows, lse, top1, dq != nullptr, st));
+    if (dq) return moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);
+    return MOMA_OK;
+}
+
+int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj, const float* b_proj,
+                 float* y, float* qkv, float* probs, float* attn_out, int N, int d, int H, int prec,
+                 moma_stream_t stream) {
+    if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !probs || !attn_out) return MOMA_E_NULL;
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
+    if (bad_prec(prec)) return MOMA_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    // qkv = x Wqkv^T + b                                   (MoMA/criterion_moco_att.py:156)
+    GemmArgs g = gemm(x, w_qkv, qkv, N, 3 * d, d, d, d, 3L * d, 0, 0, 1.f, prec);
+    g.bias = b_qkv;
+    MOMA_TRY(launch_gemm(g, st));
+    // per head: S = (q k^T) * scale                          (:159)
+    g = gemm(qkv, qkv + d, probs, N, N, hd, 3L * d, 3L * d, N, 0, 0, scale, prec);
+    g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
+    MOMA_TRY(launch_gemm(g, st));
+    MOMA_TRY(launch_softmax_rows(probs, (long)H * N, N, st));                      // :160
+    // per head: a[:, h*hd:(h+1)*hd] = P v                   (:163)
+    g = gemm(probs, qkv + 2 * d, attn_out, N, hd, N, N, 3L * d, d, 0, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    // y = a Wproj^T + b                                      (:164)
+    g = gemm(attn_out, w_proj, y, N, d, d, d, d, d, 0, 0, 1.f, prec);
+    g.bias = b_proj;
+    return hip_rc(launch_gemm(g, st));
+}
+
+size_t moma_mha_bwd_workspace_bytes(int N, int d, int H) {
+    if (N <= 0 || d <= 0 || H <= 0) return 0;
+    // dA [N,d] + dP [H,N,N] + dqkv [N,3d]
+    return align_up(((size_t)N * d + (size_t)H * N * N + (size_t)N * 3 * d) * sizeof(float), 256);
+}
+
+int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv, const float* probs,
+                 const float* attn_out, const float* dy, float* dx, float* dw_qkv, float* db_qkv, float* dw_proj,
+                 float* db_proj, void* workspace, size_t workspace_bytes, int N, int d, int H, int prec,
+                 moma_stream_t stream) {
+    if (!x || !w_qkv || !w_proj || !qkv || !probs || !attn_out || !dy || !workspace) return MOMA_E_NULL;
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
+    if (bad_prec(prec)) return MOMA_E_DTYPE;
+    if (workspace_bytes < moma_mha_bwd_workspace_bytes(N, d, H)) return MOMA_E_WORKSPACE;
+    if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* dA = (float*)workspace;
+    float* dP = dA + (size_t)N * d;
+    float* dqkv = dP + (size_t)H * N * N;
+    GemmArgs g;
+    // proj: dWproj = dy^T a ; dbproj = colsum(dy) ; dA = dy Wproj
+    if (dw_proj) {
+        g = gemm(dy, attn_out, dw_proj, d, d, N, d, d, d, 1, 1, 1.f, prec);
+        MOMA_TRY(launch_gemm(g, st));
+    }
+    if (db_proj) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
+    g = gemm(dy, w_proj, dA, N, d, d, d, d, d, 0, 1, 1.f, prec);
+    MOMA_TRY(launch_gemm(g, st));
+    // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
+    g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    // per head: dP = dA_h V^T
+    g = gemm(dA, qkv + 2 * d, dP, N, N, hd, d, 3L * d, N, 0, 0, 1.f, prec);
+    g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
+    MOMA_TRY(launch_gemm(g, st));
+    // dS = P * (dP - rowsum(dP*P)) * scale   (in place on dP)
+    MOMA_TRY(launch_softmax_bwd_rows(probs, dP, (long)H * N, N, scale, st));
+    // per head: dQ = dS K ; dK = dS^T Q
+    g = gemm(dP, qkv + d, dqkv, N, hd, N, N, 3L * d, 3L * d, 0, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    // qkv linear: dWqkv = dqkv^T x ; dbqkv = colsum(dqkv) ; dx = dqkv Wqkv
+    if (dw_qkv) {
+        g = gemm(dqkv, x, dw_qkv, 3 * d, d, N, 3L * d, d, d, 1, 1, 1.f, prec);
+        MOMA_TRY(launch_gemm(g, st));
+    }
+    if (db_qkv) MOMA_TRY(launch_colsum(dqkv, db_qkv, N, 3 * d, 3L * d, st));
+    if (dx) {
+        g = gemm(dqkv, w_qkv, dx, N, d, 3 * d, 3L * d, d, d, 0, 1, 1.f, prec);
+        MOMA_TRY(launch_gemm(g, st));
+    }
+    return MOMA_OK;
+}
+
+}  // extern "C"

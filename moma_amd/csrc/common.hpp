@@ -1,0 +1,81 @@
+// Shared device helpers and internal launch declarations for libmoma_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/moma_hip.h"
+
+namespace moma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_raw;  // storage type of a bf16 queue element
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
+    return __uint_as_float(((unsigned)v) << 16);
+}
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    // plain cast -> v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_raw*>(&b);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- generic batched GEMM:  C[m,n] (+)= alpha * sum_k A(m,k) * B(n,k) + bias[n] ----------------
+//   A(m,k) = transA ? A[k*lda + m] : A[m*lda + k]      (fp32)
+//   B(n,k) = transB ? B[k*ldb + n] : B[n*ldb + k]      (fp32 or bf16 storage)
+//   batch b adds b*strideX elements to each base pointer; split-K partial sums are combined with
+//   fp32 atomics into a C the caller has initialised (atomic != 0).
+struct GemmArgs {
+    const float* A;
+    const void* B;
+    float* C;
+    const float* bias;   // nullable, length N
+    int M, N, K;
+    long lda, ldb, ldc;
+    long strideA, strideB, strideC;
+    int batch;
+    int transA, transB;
+    float alpha;
+    int splitk;          // >= 1
+    int atomic;          // 1: atomicAdd into C
+    int b_dtype;         // MOMA_DT_*
+    int prec;            // MOMA_PREC_*
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- row-wise helpers (rowops.hip) ---------------------------------------------------------------
+hipError_t launch_softmax_rows(float* s, long rows, int cols, hipStream_t st);
+hipError_t launch_softmax_bwd_rows(const float* p, float* dp, long rows, int cols, float scale, hipStream_t st);
+hipError_t launch_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t st);
+hipError_t launch_pos_logit(const float* q, const float* k, float* out, long ld_out, int B, int d, float inv_T, hipStream_t st);
+hipError_t launch_infonce_rows(float* logits, int B, int ncols, float* loss_rows, float* lse, int32_t* top1,
+                               int write_probs, hipStream_t st);
+hipError_t launch_pos_grad_init(const float* dlogits, long ld, const float* k, float* dq, int B, int d, float inv_T,
+                                hipStream_t st);
+
+// ---- queue.hip -----------------------------------------------------------------------------------
+hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d, int qdtype, hipStream_t st);
+hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks, float m, float om, hipStream_t st);
+
+// ---- infonce_fused.hip (one-pass flash-style kernel) ----------------------------------------------
+bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec);
+size_t infonce_flash_workspace_bytes(int B, int d, int K);
+hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
+                                float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
+                                hipStream_t st);
+
+}  // namespace moma

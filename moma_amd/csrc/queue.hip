@@ -1,0 +1,93 @@
+// K3 ring-buffer enqueue and K4 multi-tensor EMA: pure HBM streaming kernels (16 B per lane where the
+// operands are 16-B aligned).
+#include "common.hpp"
+
+namespace moma {
+namespace {
+
+// queue[(index + i) mod K, :] = rows[i, :]      (MoMA/mem_moco.py:17-27)
+// one workgroup per source row; rows whose slot is rewritten by a later row (n > K) are skipped so the
+// result equals a serial index_copy_ (last writer wins) without a write race.
+template <typename TQ, bool VEC4>
+__global__ __launch_bounds__(256) void enqueue_kernel(TQ* __restrict__ queue, const float* __restrict__ rows, int n,
+                                                       int64_t index, int K, int d) {
+    const int i = blockIdx.x;
+    if ((int64_t)i + K < n) return;
+    const int64_t slot = (index + i) % K;
+    const float* src = rows + (int64_t)i * d;
+    TQ* dst = queue + slot * d;
+    if constexpr (VEC4) {
+        for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            if constexpr (sizeof(TQ) == 4) {
+                *reinterpret_cast<float4*>(dst + c) = v;
+            } else {
+                ushort4 o;
+                o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(dst + c) = o;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) {
+            if constexpr (sizeof(TQ) == 4) dst[c] = src[c];
+            else dst[c] = f32_to_bf16(src[c]);
+        }
+    }
+}
+
+// ema = fma(1-m, p, ema*m) over a table of tensors   (learning/contrast_trainer.py:207-211)
+__global__ __launch_bounds__(256) void ema_kernel(const int64_t* __restrict__ table, int n_tensors, float m, float om) {
+    const int64_t blk = blockIdx.x;
+    // binary search: last t with first_block[t] <= blk
+    int lo = 0, hi = n_tensors - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 4 + 3] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    float* __restrict__ e = reinterpret_cast<float*>(table[lo * 4 + 0]);
+    const float* __restrict__ p = reinterpret_cast<const float*>(table[lo * 4 + 1]);
+    const int64_t numel = table[lo * 4 + 2];
+    const int64_t off = (blk - table[lo * 4 + 3]) * MOMA_EMA_BLOCK_ELEMS;
+    const int64_t rem = numel - off;
+    const bool vec = (((uintptr_t)e | (uintptr_t)p) & 15) == 0;
+    if (vec && rem >= MOMA_EMA_BLOCK_ELEMS) {
+#pragma unroll
+        for (int i = 0; i < MOMA_EMA_BLOCK_ELEMS / (256 * 4); ++i) {
+            const int64_t idx = off + (int64_t)(i * 256 + threadIdx.x) * 4;
+            float4 ev = *reinterpret_cast<const float4*>(e + idx);
+            const float4 pv = *reinterpret_cast<const float4*>(p + idx);
+            ev.x = fmaf(om, pv.x, ev.x * m);
+            ev.y = fmaf(om, pv.y, ev.y * m);
+            ev.z = fmaf(om, pv.z, ev.z * m);
+            ev.w = fmaf(om, pv.w, ev.w * m);
+            *reinterpret_cast<float4*>(e + idx) = ev;
+        }
+    } else {
+        const int64_t end = rem < MOMA_EMA_BLOCK_ELEMS ? rem : MOMA_EMA_BLOCK_ELEMS;
+        for (int64_t j = threadIdx.x; j < end; j += 256) e[off + j] = fmaf(om, p[off + j], e[off + j] * m);
+    }
+}
+}  // namespace
+
+hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d, int qdtype, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const bool a16 = (((uintptr_t)queue | (uintptr_t)rows) & 15) == 0;
+    dim3 grid(n), block(256);
+    if (qdtype == MOMA_DT_BF16) {
+        if (a16 && d % 8 == 0) hipLaunchKernelGGL((enqueue_kernel<bf16_raw, true>), grid, block, 0, st, (bf16_raw*)queue, rows, n, index, K, d);
+        else hipLaunchKernelGGL((enqueue_kernel<bf16_raw, false>), grid, block, 0, st, (bf16_raw*)queue, rows, n, index, K, d);
+    } else {
+        if (a16 && d % 4 == 0) hipLaunchKernelGGL((enqueue_kernel<float, true>), grid, block, 0, st, (float*)queue, rows, n, index, K, d);
+        else hipLaunchKernelGGL((enqueue_kernel<float, false>), grid, block, 0, st, (float*)queue, rows, n, index, K, d);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks, float m, float om, hipStream_t st) {
+    if (n_tensors <= 0 || total_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, n_tensors, m, om);
+    return hipGetLastError();
+}
+
+}  // namespace moma

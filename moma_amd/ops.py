@@ -1,0 +1,242 @@
+"""torch-facing wrappers of the C ABI (include/moma_hip.h): device pointers and the current HIP stream
+are handed to libmoma_hip.so; autograd Functions wire the hand-written backward kernels in.
+
+PyTorch is plumbing here (memory, streams, autograd graph); all arithmetic of the hot path happens in
+the HIP library.  Every wrapper refuses CPU tensors: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F32, PREC_BF16, PREC_F32, EMA_BLOCK_ELEMS, MomaHipError, check
+
+_PREC = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, PREC_F32: PREC_F32,
+         "bf16": PREC_BF16, "bfloat16": PREC_BF16, PREC_BF16: PREC_BF16}
+
+
+def prec_code(p) -> int:
+    try:
+        return _PREC[p]
+    except KeyError:
+        raise ValueError(f"unknown precision {p!r}; use 'fp32' or 'bf16'")
+
+
+def _qdtype(queue: torch.Tensor) -> int:
+    if queue.dtype == torch.float32:
+        return DT_F32
+    if queue.dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"queue dtype must be float32 or bfloat16, got {queue.dtype}")
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise MomaHipError(f"{name}: the MoMA hot path runs only on the GPU (HIP library); got a "
+                           f"{'CPU tensor' if isinstance(t, torch.Tensor) else type(t)}. No CPU fallback exists.")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# K4 multi-tensor EMA   (learning/contrast_trainer.py:207-211)
+# ------------------------------------------------------------------------------------------------
+class EmaTable:
+    """Device-side pointer table for one (model, model_ema) pair; rebuilt if any tensor moves."""
+
+    def __init__(self, params: Sequence[torch.Tensor], params_ema: Sequence[torch.Tensor]):
+        params, params_ema = list(params), list(params_ema)
+        # zip() semantics of the reference: stops at the shorter list; shapes must match pairwise
+        n = min(len(params), len(params_ema))
+        rows, first = [], 0
+        self.keys = []
+        for p, e in zip(params[:n], params_ema[:n]):
+            if p.shape != e.shape:
+                raise RuntimeError(f"The size of tensor a {tuple(e.shape)} must match the size of tensor b "
+                                   f"{tuple(p.shape)} (momentum_update needs identical architectures)")
+            _dev(p, "param"); _dev(e, "param_ema")
+            if e.numel() == 0:
+                continue
+            rows.append((e.data_ptr(), p.data_ptr(), e.numel(), first))
+            first += (e.numel() + EMA_BLOCK_ELEMS - 1) // EMA_BLOCK_ELEMS
+            self.keys.append((e.data_ptr(), p.data_ptr(), e.numel()))
+        self.n = len(rows)
+        self.total_blocks = first
+        dev = params[0].device if n else torch.device("cuda")
+        self.table = (torch.tensor(rows, dtype=torch.int64).reshape(-1, 4).to(dev) if rows
+                      else torch.zeros(0, 4, dtype=torch.int64, device=dev))
+
+    def matches(self, params, params_ema) -> bool:
+        keys = [(e.data_ptr(), p.data_ptr(), e.numel()) for p, e in zip(params, params_ema) if e.numel()]
+        return keys == self.keys
+
+
+def ema_update_(table: EmaTable, m: float) -> None:
+    """ema <- fma(fl32(1-m), p, ema*fl32(m)) for every tensor of the table, one launch."""
+    lib = _lib.load()
+    if table.n == 0:
+        return
+    check(lib.moma_ema_multi(_ptr(table.table), table.n, table.total_blocks, float(m), float(1.0 - m), _stream()),
+          "moma_ema_multi")
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 ring-buffer enqueue   (MoMA/mem_moco.py:17-27)
+# ------------------------------------------------------------------------------------------------
+def enqueue_(queue: torch.Tensor, rows: torch.Tensor, index: int) -> None:
+    lib = _lib.load()
+    _dev(queue, "queue", None); _dev(rows, "rows")
+    K, d = queue.shape
+    if rows.dim() != 2 or rows.shape[1] != d:
+        raise ValueError(f"rows must be [n,{d}], got {tuple(rows.shape)}")
+    check(lib.moma_enqueue(_ptr(queue), _ptr(rows), rows.shape[0], int(index), K, d, _qdtype(queue), _stream()),
+          "moma_enqueue")
+
+
+# ------------------------------------------------------------------------------------------------
+# K2 InfoNCE
+# ------------------------------------------------------------------------------------------------
+def _check_qk(q, k, queue):
+    _dev(q, "q"); _dev(k, "k"); _dev(queue, "queue", None)
+    if q.dim() != 2 or q.shape != k.shape or queue.dim() != 2 or queue.shape[1] != q.shape[1]:
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} queue {tuple(queue.shape)}")
+
+
+class _InfoNCELogits(torch.autograd.Function):
+    """[B,K+1] logits of BaseMoCo._compute_logit (MoMA/mem_moco.py:29-49) with the backward w.r.t. q."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T, prec):
+        lib = _lib.load()
+        q = q.contiguous(); k = k.contiguous()
+        _check_qk(q, k, queue)
+        B, d = q.shape
+        K = queue.shape[0]
+        out = torch.empty(B, K + 1, device=q.device, dtype=torch.float32)
+        check(lib.moma_infonce_logits(_ptr(q), _ptr(k), _ptr(queue), _ptr(out), B, d, K, float(1.0 / T),
+                                      _qdtype(queue), prec, _stream()), "moma_infonce_logits")
+        ctx.save_for_backward(k, queue)
+        ctx.T, ctx.prec = T, prec
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.load()
+        k, queue = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        B, d = k.shape
+        K = queue.shape[0]
+        dq = torch.empty(B, d, device=k.device, dtype=torch.float32)
+        check(lib.moma_infonce_logits_bwd(_ptr(dlogits), _ptr(k), _ptr(queue), _ptr(dq), B, d, K,
+                                          float(1.0 / ctx.T), _qdtype(queue), ctx.prec, _stream()),
+              "moma_infonce_logits_bwd")
+        return dq, None, None, None, None
+
+
+def infonce_logits(q, k, queue, T: float, prec="fp32") -> torch.Tensor:
+    return _InfoNCELogits.apply(q, k, queue, float(T), prec_code(prec))
+
+
+class _InfoNCEFused(torch.autograd.Function):
+    """One pass over the queue: per-row CE(label 0) loss, lse, top-1 flag and d(sum loss)/dq."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T, prec):
+        lib = _lib.load()
+        q = q.contiguous(); k = k.contiguous()
+        _check_qk(q, k, queue)
+        B, d = q.shape
+        K = queue.shape[0]
+        dev = q.device
+        need_grad = ctx.needs_input_grad[0]
+        loss_rows = torch.empty(B, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, device=dev, dtype=torch.float32)
+        top1 = torch.empty(B, device=dev, dtype=torch.int32)
+        dq = torch.empty(B, d, device=dev, dtype=torch.float32) if need_grad else None
+        qd = _qdtype(queue)
+        ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec)
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        check(lib.moma_infonce_fused(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
+                                     _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream()),
+              "moma_infonce_fused")
+        if need_grad:
+            ctx.save_for_backward(dq)
+        ctx.mark_non_differentiable(lse, top1)
+        return loss_rows, lse, top1
+
+    @staticmethod
+    def backward(ctx, g_loss, g_lse, g_top1):
+        (dq,) = ctx.saved_tensors
+        return dq * g_loss.unsqueeze(1), None, None, None, None
+
+
+def infonce_fused(q, k, queue, T: float, prec="fp32") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (loss_rows [B], lse [B], top1 [B] int32).  loss_kd = loss_rows.mean()."""
+    return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec))
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 batch-token multi-head attention   (MoMA/criterion_moco_att.py:153-167)
+# ------------------------------------------------------------------------------------------------
+class _MHA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_qkv, b_qkv, w_proj, b_proj, H, prec):
+        lib = _lib.load()
+        x = x.contiguous()
+        for t, nm in ((x, "x"), (w_qkv, "qkv.weight"), (w_proj, "proj.weight"), (b_proj, "proj.bias")):
+            _dev(t, nm)
+        if b_qkv is not None:
+            _dev(b_qkv, "qkv.bias")
+        N, d = x.shape
+        if w_qkv.shape != (3 * d, d) or w_proj.shape != (d, d) or d % H:
+            raise ValueError(f"bad attention shapes: x {tuple(x.shape)} Wqkv {tuple(w_qkv.shape)} H={H}")
+        dev = x.device
+        y = torch.empty(N, d, device=dev, dtype=torch.float32)
+        qkv = torch.empty(N, 3 * d, device=dev, dtype=torch.float32)
+        probs = torch.empty(H, N, N, device=dev, dtype=torch.float32)
+        attn_out = torch.empty(N, d, device=dev, dtype=torch.float32)
+        check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
+                               _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, w_qkv, w_proj, qkv, probs, attn_out)
+        ctx.H, ctx.prec, ctx.has_bqkv = H, prec, b_qkv is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_qkv, w_proj, qkv, probs, attn_out = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, d = x.shape
+        H = ctx.H
+        dev = x.device
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dw_qkv = torch.empty_like(w_qkv) if need[1] else None
+        db_qkv = torch.empty(3 * d, device=dev, dtype=torch.float32) if (need[2] and ctx.has_bqkv) else None
+        dw_proj = torch.empty_like(w_proj) if need[3] else None
+        db_proj = torch.empty(d, device=dev, dtype=torch.float32) if need[4] else None
+        ws_bytes = lib.moma_mha_bwd_workspace_bytes(N, d, H)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(attn_out), _ptr(dy),
+                               _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
+                               ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
+        return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None
+
+
+def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads: int, prec="fp32") -> torch.Tensor:
+    return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec))

@@ -1,0 +1,225 @@
+"""GPU parity tests: every kernel is called through the C ABI (moma_amd.ops -> ctypes -> libmoma_hip.so)
+and compared with (a) the golden vectors captured from the reference and (b) the CPU oracle on seeded
+inputs.  Tolerances are stated per test: bit-exact for copies / indices / EMA, 1e-5-class for the fp32
+policy (exact fp32 fma chains, different summation order than ATen), 2e-2-class for the bf16 policy."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import moma_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd import ops as _ops
+    from moma_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+# ------------------------------------------------------------------------------------------------ K4
+def test_ema_golden_bit_exact(ops, golden_dir):
+    g = _g(golden_dir, "g3_ema.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        m = float(g[p + "m"]); n = int(g[p + "n"])
+        ps = [_t(g[p + f"p{i}"]) for i in range(n)]
+        es = [_t(g[p + f"e{i}"]) for i in range(n)]
+        table = ops.EmaTable(ps, es)
+        for _ in range(3):
+            ops.ema_update_(table, m)
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert np.array_equal(es[i].cpu().numpy(), g[p + f"r{i}"]), (ci, i)
+
+
+def test_ema_large_ragged_vs_oracle(ops):
+    rng = np.random.default_rng(0)
+    sizes = [1, 5, 4096, 4097, 8192 + 3, 1_000_003, 32 * 3 * 3 * 3, 1280 * 320]
+    ps = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    es = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    tp = [_t(a) for a in ps]; te = [_t(a) for a in es]
+    # an unaligned view exercises the scalar path
+    big = torch.randn(10_001, device="cuda"); bige = torch.randn(10_001, device="cuda")
+    tp.append(big[1:]); te.append(bige[1:])
+    ps.append(big[1:].cpu().numpy().copy()); es.append(bige[1:].cpu().numpy().copy())
+    table = ops.EmaTable([t.contiguous() if not t.is_contiguous() else t for t in tp], te)
+    for m in (0.999, 0.999):
+        ops.ema_update_(table, m)
+        O.momentum_update(ps, es, m)
+    torch.cuda.synchronize()
+    for a, b in zip(te, es):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+# ------------------------------------------------------------------------------------------------ K3
+def test_enqueue_golden_traces_bit_exact(ops, golden_dir):
+    g = _g(golden_dir, "g2_queue.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        K, d, B, n, steps = [int(v) for v in g[p + "cfg"]]
+        queue = _t(g[p + "memory0"])
+        index = 0
+        for s in range(steps):
+            rows = _t(g[p + "all_k"][s])
+            ops.enqueue_(queue, rows, index)
+            index = (index + n) % K
+            assert index == int(g[p + "index"][s])
+            assert np.array_equal(queue.cpu().numpy(), g[p + "memory"][s]), (ci, s)
+
+
+@pytest.mark.parametrize("K,d,n,index", [(65536, 512, 256, 65536 - 100), (65536, 1280, 256, 0), (1000, 36, 77, 990),
+                                          (64, 5, 200, 3)])
+def test_enqueue_wrap_vs_oracle(ops, K, d, n, index):
+    rng = np.random.default_rng(1)
+    q0 = rng.standard_normal((K, d)).astype(np.float32)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    queue = _t(q0)
+    ops.enqueue_(queue, _t(rows), index)
+    ref = q0.copy()
+    O.update_memory(ref, rows, index)
+    assert np.array_equal(queue.cpu().numpy(), ref)
+    # bf16 queue: rows rounded to nearest even, untouched rows unchanged
+    qb = _t(q0, torch.bfloat16)
+    before = qb.clone()
+    ops.enqueue_(qb, _t(rows), index)
+    ids = np.unique(O.enqueue_ids(index, n, K))
+    refb = before.clone()
+    last = {}
+    for i, j in enumerate(O.enqueue_ids(index, n, K)):
+        last[int(j)] = i
+    for j, i in last.items():
+        refb[j] = _t(rows[i]).to(torch.bfloat16)
+    assert torch.equal(qb, refb)
+    assert len(ids) == min(n, K)
+
+
+# ------------------------------------------------------------------------------------------------ K2
+@pytest.mark.parametrize("prec,rtol,atol", [("fp32", 2e-5, 2e-5), ("bf16", 2e-2, 2e-2)])
+def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
+    g = _g(golden_dir, "g4_infonce.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        B, d, K = [int(v) for v in g[p + "cfg"]]
+        q = _t(g[p + "q"]).requires_grad_(True)
+        k = _t(g[p + "k"]); mem = _t(g[p + "memory0"])
+        logits = ops.infonce_logits(q, k, mem, 0.15, prec)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[p + "logits"], rtol=rtol, atol=atol)
+        loss = torch.nn.functional.cross_entropy(logits, torch.zeros(B, dtype=torch.long, device="cuda"))
+        loss.backward()
+        tol_loss = 1e-5 if prec == "fp32" else 1e-3
+        assert abs(loss.item() - float(g[p + "loss"])) < tol_loss * max(1.0, abs(float(g[p + "loss"])))
+        np.testing.assert_allclose(q.grad.cpu().numpy(), g[p + "dq"], rtol=rtol * 10, atol=atol * 0.05)
+        # fused path: same loss, accuracy and gradient without materialised logits at the API
+        q2 = _t(g[p + "q"]).requires_grad_(True)
+        loss_rows, lse, top1 = ops.infonce_fused(q2, k, mem, 0.15, prec)
+        loss2 = loss_rows.mean()
+        loss2.backward()
+        assert abs(loss2.item() - float(g[p + "loss"])) < tol_loss * max(1.0, abs(float(g[p + "loss"])))
+        assert abs(100.0 * top1.float().mean().item() - float(g[p + "acc"])) < 1e-4
+        np.testing.assert_allclose(q2.grad.cpu().numpy(), g[p + "dq"], rtol=rtol * 10, atol=atol * 0.05)
+
+
+@pytest.mark.parametrize("B,d,K,qdt", [(64, 512, 4096, "fp32"), (37, 96, 1000, "fp32"), (256, 512, 8192, "bf16"),
+                                       (16, 1280, 2048, "fp32"), (1, 64, 100, "fp32")])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
+    rng = np.random.default_rng(B + d + K)
+    q = rng.standard_normal((B, d)).astype(np.float32) * 0.7 / np.sqrt(d) * np.sqrt(d) / np.sqrt(d)
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    tq = _t(q).requires_grad_(True)
+    tk = _t(k)
+    tqueue = _t(queue, torch.bfloat16 if qdt == "bf16" else torch.float32)
+    queue_eff = tqueue.float().cpu().numpy()
+    T = 0.15
+    ref_logits = O.compute_logit(q, k, queue_eff, T, dtype=np.float64)
+    ref = O.infonce_loss(ref_logits)
+    ref_dq = O.infonce_grad(q, k, queue_eff, T) * B          # d(sum loss)/dq
+    if prec == "fp32":
+        rtol, atol, ltol = 1e-5, 2e-5, 2e-5
+    else:
+        rtol, atol, ltol = 2e-2, 2e-2, 1e-3
+    logits = ops.infonce_logits(tq, tk, tqueue, T, prec)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits, rtol=rtol, atol=atol)
+    loss_rows, lse, top1 = ops.infonce_fused(tq, tk, tqueue, T, prec)
+    assert abs(loss_rows.mean().item() - ref["loss"]) < ltol * max(1.0, abs(ref["loss"]))
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=ltol, atol=ltol * 5)
+    if prec == "fp32":
+        assert np.array_equal(top1.cpu().numpy().astype(bool), ref["top1"])
+    loss_rows.sum().backward()
+    scale = np.abs(ref_dq).max()
+    np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=(2e-5 if prec == "fp32" else 2e-2) * scale)
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("prec,rtol,atol", [("fp32", 2e-4, 2e-5), ("bf16", 5e-2, 2e-2)])
+def test_mha_golden(ops, golden_dir, prec, rtol, atol):
+    g = _g(golden_dir, "g1_attention.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        n, d, h = [int(v) for v in g[p + "shape"]]
+        x = _t(g[p + "x"]).requires_grad_(True)
+        ws = [_t(g[p + nm]).requires_grad_(True) for nm in ("w_qkv", "b_qkv", "w_proj", "b_proj")]
+        y = ops.mha(x, *ws, h, prec)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[p + "y"], rtol=rtol, atol=atol, err_msg=f"case {ci} y")
+        (y * _t(g[p + "dy"])).sum().backward()
+        for t, nm in zip([x] + ws, ("dx", "d_wqkv", "d_bqkv", "d_wproj", "d_bproj")):
+            ref = g[p + nm]
+            np.testing.assert_allclose(t.grad.cpu().numpy(), ref, rtol=rtol, atol=atol * max(1.0, np.abs(ref).max()),
+                                       err_msg=f"case {ci} {nm}")
+
+
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (64, 384, 8), (100, 1280, 4), (300, 256, 4)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mha_vs_oracle(ops, N, d, H, prec):
+    rng = np.random.default_rng(N + d)
+    x = O.l2_normalize(rng.standard_normal((N, d)).astype(np.float32))
+    bound = 1.0 / np.sqrt(d)
+    w_qkv = rng.uniform(-bound, bound, (3 * d, d)).astype(np.float32) * 4
+    b_qkv = rng.uniform(-bound, bound, 3 * d).astype(np.float32)
+    w_proj = rng.uniform(-bound, bound, (d, d)).astype(np.float32)
+    b_proj = rng.uniform(-bound, bound, d).astype(np.float32)
+    dy = rng.standard_normal((N, d)).astype(np.float32)
+    ref = O.attention_bwd(x, w_qkv, b_qkv, w_proj, b_proj, H, dy, dtype=np.float64)
+    tx = _t(x).requires_grad_(True)
+    tw = [_t(a).requires_grad_(True) for a in (w_qkv, b_qkv, w_proj, b_proj)]
+    y = ops.mha(tx, *tw, H, prec)
+    (y * _t(dy)).sum().backward()
+    tol = 3e-5 if prec == "fp32" else 3e-2
+    for t, nm in zip([y.detach()] + [a.grad for a in [tx] + tw], ("y", "dx", "d_wqkv", "d_bqkv", "d_wproj", "d_bproj")):
+        r = ref[nm]
+        err = np.abs(t.cpu().numpy() - r).max() / max(np.abs(r).max(), 1e-12)
+        assert err < tol, (nm, err)
+
+
+# ------------------------------------------------------------------------------------------------ ABI
+def test_abi_argument_checks(ops):
+    from moma_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    assert lib.moma_version() == 1
+    q = torch.zeros(4, 8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.moma_enqueue(None, C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 0, st) == -1
+    assert lib.moma_enqueue(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), 4, 9, 8, 8, 0, st) == -2
+    assert lib.moma_enqueue(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 7, st) == -3
+    assert lib.moma_mha_fwd(*([C.c_void_p(q.data_ptr())] * 9), 4, 8, 3, 0, st) == -2
+    assert b"workspace" in lib.moma_error_string(-5)
+    with pytest.raises(_lib.MomaHipError):
+        ops.enqueue_(torch.zeros(4, 8), torch.zeros(2, 8), 0)      # CPU tensors are refused, no fallback
