@@ -1,0 +1,95 @@
+"""MoCo-style feature queue of the MoMA step, backed by the HIP library.
+
+Drop-in for the reference's MoMA/mem_moco.py (`BaseMoCo` :6-66, `MoCo` :69-100, `build_mem` :256-272):
+same constructor arguments, buffer name (`memory`), attributes (`K`, `T`, `index`) and
+`forward(q, k, all_k=None) -> (logits [B,K+1], labels [B])`.  The op chains it replaces:
+
+  _compute_logit  (bmm + mm + transpose + cat + div)   -> moma_infonce_logits        (K2)
+  _update_memory  (arange + fmod + index_copy_)        -> moma_enqueue               (K3)
+  _update_pointer (host integer)                       -> unchanged, bit-exact contract
+
+plus `forward_fused`, the one-pass replacement of MoCo.forward + CrossEntropyLoss(label 0) + top-1
+(helper/loops_moma.py:322,331-335): no [B,K+1] logits, no queue clone, dq produced from the pre-enqueue
+queue in the same pass.  All tensors must live on the GPU; there is no CPU path.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class BaseMoCo(nn.Module):
+    """base class for MoCo-style memory cache (reference MoMA/mem_moco.py:6-66)"""
+
+    def __init__(self, K=65536, T=0.07, precision="fp32"):
+        super().__init__()
+        self.K = K
+        self.T = T
+        self.index = 0            # host-side ring pointer; not part of state_dict (as in the reference)
+        self.precision = precision
+
+    def _update_pointer(self, bsz):
+        self.index = (self.index + bsz) % self.K
+
+    def _update_memory(self, k, queue):
+        """queue[(index + i) mod K] = k[i]   (reference :17-27)"""
+        with torch.no_grad():
+            ops.enqueue_(queue, k.detach().contiguous().float(), self.index)
+
+    def _compute_logit(self, q, k, queue):
+        """[B,K+1] logits: pos | neg, divided by T   (reference :29-49)"""
+        return ops.infonce_logits(q, k, queue, self.T, self.precision)
+
+
+class MoCo(BaseMoCo):
+    """Single-modal MoCo-style cache (reference MoMA/mem_moco.py:69-100).
+
+    queue_dtype=torch.bfloat16 stores the K x d queue in 2-byte rows (half the HBM traffic of K2); with
+    precision='bf16' this is numerically identical to fp32 storage because the bf16 MFMA path rounds the
+    keys to bf16 at load time anyway.
+    """
+
+    def __init__(self, n_dim, K=65536, T=0.07, mem_name="memory", queue_dtype=torch.float32, precision="fp32"):
+        super().__init__(K, T, precision)
+        # same RNG consumption and normalisation as the reference (:73-75)
+        self.register_buffer(mem_name, torch.randn(K, n_dim))
+        self.memory = F.normalize(self.memory)
+        if queue_dtype != torch.float32:
+            self.memory = self.memory.to(queue_dtype)
+
+    def forward(self, q, k, all_k=None):
+        """Reference-compatible: materialised logits and zero labels, then enqueue (:77-100)."""
+        bsz = q.size(0)
+        k = k.detach()
+        # the backward of the logits needs the PRE-enqueue queue -> snapshot, as the reference does (:89)
+        queue = self.memory.clone().detach() if (torch.is_grad_enabled() and q.requires_grad) else self.memory
+        logits = self._compute_logit(q, k, queue)
+        labels = torch.zeros(bsz, dtype=torch.long, device=q.device)
+        all_k = all_k if all_k is not None else k
+        self._update_memory(all_k, self.memory)
+        self._update_pointer(all_k.size(0))
+        return logits, labels
+
+    def forward_fused(self, q, k, all_k=None):
+        """One pass over the queue -> (loss_kd, top-1 accuracy in percent [1]); then enqueue.
+
+        loss_kd == CrossEntropyLoss(logits, zeros) of the reference loop; its gradient w.r.t. q is produced
+        by the same kernel from the pre-enqueue queue, so no clone is needed."""
+        k = k.detach()
+        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory, self.T, self.precision)
+        all_k = all_k if all_k is not None else k
+        self._update_memory(all_k, self.memory)
+        self._update_pointer(all_k.size(0))
+        return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
+
+
+def build_mem(opt):
+    """Factory on opt.mem (reference MoMA/mem_moco.py:256-272).  Extra, optional opt fields:
+    `moma_prec` ('fp32' | 'bf16') and `queue_dtype` ('fp32' | 'bf16')."""
+    prec = getattr(opt, "moma_prec", "fp32")
+    qdt = {"fp32": torch.float32, "bf16": torch.bfloat16}[getattr(opt, "queue_dtype", "fp32")]
+    if opt.mem in ("MoCoSSTT", "MoCoST", "MoCoAtt"):
+        # dual-queue / cross-attention memories: SURVEY section 8(f) rows n1/n2, not on the --distill moma loop
+        raise NotImplementedError("mem not built yet: {}".format(opt.mem))
+    return MoCo(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)   # reference default branch

@@ -1,0 +1,138 @@
+"""EfficientNet-B0 backbone with the MoMA feature-list contract
+`model(x, is_feat=True) -> ([reduction_1..4, head, pooled[B,1280,1,1]], logits)`, `get_feat_modules()`.
+
+Own implementation of the published architecture (MBConv + squeeze-excite + swish, TF "same" padding,
+stochastic depth).  Parameter names (_conv_stem, _bn0, _blocks.N._expand_conv/_depthwise_conv/_se_reduce/
+_se_expand/_project_conv/_bn0.._bn2, _conv_head, _bn1, classifier_.1) match the reference's checkpoints
+(models/efficientnet_pytorch/model.py:154-222) so they load unchanged.  The convolutions run on
+PyTorch-ROCm / MIOpen: backbones are out of scope as kernels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# (repeats, kernel, stride, expand, cin, cout, se_ratio) -- EfficientNet-B0 stage table
+_B0_STAGES = [
+    (1, 3, 1, 1, 32, 16, 0.25),
+    (2, 3, 2, 6, 16, 24, 0.25),
+    (2, 5, 2, 6, 24, 40, 0.25),
+    (3, 3, 2, 6, 40, 80, 0.25),
+    (3, 5, 1, 6, 80, 112, 0.25),
+    (4, 5, 2, 6, 112, 192, 0.25),
+    (1, 3, 1, 6, 192, 320, 0.25),
+]
+_BN_MOM, _BN_EPS = 0.01, 1e-3
+
+
+class SamePadConv2d(nn.Conv2d):
+    """Conv2d with TensorFlow 'SAME' padding computed from the input size at call time."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, groups=1, bias=True):
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=0, groups=groups, bias=bias)
+
+    def forward(self, x):
+        ih, iw = x.shape[-2:]
+        kh, kw = self.kernel_size
+        sh, sw = self.stride
+        ph = max((math.ceil(ih / sh) - 1) * sh + kh - ih, 0)
+        pw = max((math.ceil(iw / sw) - 1) * sw + kw - iw, 0)
+        if ph % 2 == 0 and pw % 2 == 0:
+            return F.conv2d(x, self.weight, self.bias, self.stride, (ph // 2, pw // 2), self.dilation, self.groups)
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+def _drop_connect(x, p, training):
+    if not training or not p:
+        return x
+    keep = 1.0 - p
+    mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
+    return x / keep * mask
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, kernel, stride, expand, cin, cout, se_ratio):
+        super().__init__()
+        mid = cin * expand
+        self.expand, self.stride, self.cin, self.cout = expand, stride, cin, cout
+        if expand != 1:
+            self._expand_conv = SamePadConv2d(cin, mid, 1, bias=False)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
+        self._depthwise_conv = SamePadConv2d(mid, mid, kernel, stride=stride, groups=mid, bias=False)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
+        sq = max(1, int(cin * se_ratio))
+        self._se_reduce = SamePadConv2d(mid, sq, 1)
+        self._se_expand = SamePadConv2d(sq, mid, 1)
+        self._project_conv = SamePadConv2d(mid, cout, 1, bias=False)
+        self._bn2 = nn.BatchNorm2d(cout, momentum=_BN_MOM, eps=_BN_EPS)
+
+    def forward(self, x, drop_connect_rate=None):
+        inp = x
+        if self.expand != 1:
+            x = F.silu(self._bn0(self._expand_conv(x)))
+        x = F.silu(self._bn1(self._depthwise_conv(x)))
+        s = F.adaptive_avg_pool2d(x, 1)
+        s = self._se_expand(F.silu(self._se_reduce(s)))
+        x = torch.sigmoid(s) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.cin == self.cout:
+            x = _drop_connect(x, drop_connect_rate, self.training) + inp
+        return x
+
+
+class EfficientNet(nn.Module):
+    def __init__(self, num_classes=1000, dropout_rate=0.2, drop_connect_rate=0.2, in_channels=3):
+        super().__init__()
+        self.drop_connect_rate = drop_connect_rate
+        self._conv_stem = SamePadConv2d(in_channels, 32, 3, stride=2, bias=False)
+        self._bn0 = nn.BatchNorm2d(32, momentum=_BN_MOM, eps=_BN_EPS)
+        blocks = []
+        for rep, k, s, e, cin, cout, se in _B0_STAGES:
+            blocks.append(MBConvBlock(k, s, e, cin, cout, se))
+            blocks += [MBConvBlock(k, 1, e, cout, cout, se) for _ in range(rep - 1)]
+        self._blocks = nn.ModuleList(blocks)
+        self._conv_head = SamePadConv2d(320, 1280, 1, bias=False)
+        self._bn1 = nn.BatchNorm2d(1280, momentum=_BN_MOM, eps=_BN_EPS)
+        self._avg_pooling = nn.AdaptiveAvgPool2d(1)
+        self.classifier_ = nn.Sequential(nn.Dropout(dropout_rate), nn.Linear(1280, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+
+    def extract_endpoints(self, x):
+        feats = []
+        x = F.silu(self._bn0(self._conv_stem(x)))
+        prev = x
+        nb = len(self._blocks)
+        for i, blk in enumerate(self._blocks):
+            rate = self.drop_connect_rate * float(i) / nb if self.drop_connect_rate else self.drop_connect_rate
+            x = blk(x, drop_connect_rate=rate)
+            if prev.size(2) > x.size(2):
+                feats.append(prev)
+            prev = x
+        feats.append(F.silu(self._bn1(self._conv_head(x))))
+        return feats
+
+    def get_feat_modules(self):
+        return nn.ModuleList([self._conv_stem, self._bn0, self._blocks, self._conv_head, self._bn1, self.classifier_])
+
+    def forward(self, x, is_feat=False):
+        out = self.extract_endpoints(x)
+        pooled = self._avg_pooling(out[-1])
+        out.append(pooled)
+        logits = self.classifier_(pooled.flatten(start_dim=1))
+        return (out, logits) if is_feat else logits
+
+
+def efficientnet_b0(num_classes=1000, **kw):
+    return EfficientNet(num_classes=num_classes, **kw)

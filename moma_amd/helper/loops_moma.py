@@ -1,0 +1,163 @@
+"""The MoMA contrastive-distillation step loop (reference: helper/loops_moma.py:221-373, moma branch
+:308-335) and a minimal validation loop (:448-529).
+
+Order of operations per batch is the reference's: student fwd, teacher fwd #1, CE + KL terms,
+EMA of the teacher (K4), Shuffle-BN key encoding (teacher fwd #2), heads, batch-token attention (K1),
+InfoNCE over the queue + enqueue (K2, K3), weighted sum, backward, optimizer step.  Differences, all
+performance-only: the per-step `.item()` host syncs (:351,355) are deferred to print time; `atts_k` /
+`atts_queue` run under no_grad (their outputs are detached / enqueued under no_grad in the reference, so
+their grads are None either way -- Q6); the KD term uses the one-pass fused kernel unless
+opt.moma_fused is False, in which case the reference call sequence contrast(...) -> CrossEntropyLoss runs
+on materialised logits.
+"""
+from __future__ import print_function
+
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+from .util import AverageMeter, accuracy
+
+
+def _set_bn_train(m):
+    if m.__class__.__name__.find("BatchNorm") != -1:
+        m.train()
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def _same_arch(a, b):
+    pa, pb = list(a.parameters()), list(b.parameters())
+    return len(pa) == len(pb) and all(x.shape == y.shape for x, y in zip(pa, pb))
+
+
+def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer, contrast, optimizer, opt):
+    """one epoch distillation; returns (top1.avg, losses.avg) like the reference."""
+    for module in module_list:
+        module.train()
+    module_list[-1].eval()                      # teacher in eval for its first forward (:227)
+
+    criterion_cls, criterion_div, criterion_kd = criterion_list[0], criterion_list[1], criterion_list[2]
+    model_s, model_t = module_list[0], module_list[-1]
+
+    batch_time, losses, top1 = AverageMeter(), AverageMeter(), AverageMeter()
+    n_batch = len(train_loader)
+    amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(getattr(opt, "amp", None))
+    scaler = getattr(opt, "_grad_scaler", None)
+    fused = getattr(opt, "moma_fused", True)
+    dev = getattr(opt, "device", None)
+    if dev is None:
+        dev = torch.device("cuda", opt.gpu if (opt.gpu is not None and opt.multiprocessing_distributed) else 0) \
+            if torch.cuda.is_available() else torch.device("cpu")
+    ema_ok = None
+    kd_params = None
+    trace = getattr(opt, "trace", None)
+
+    end = time.time()
+    for idx, data in enumerate(train_loader):
+        images, labels = data
+        images = images.to(dev, non_blocking=True)
+        labels = labels.to(dev, non_blocking=True)
+        if getattr(opt, "channels_last", False):
+            images = images.contiguous(memory_format=torch.channels_last)
+
+        # =================== forward =====================
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            feat_s, logit_s = model_s(images, is_feat=True)
+            with torch.no_grad():
+                feat_t, logit_t = model_t(images, is_feat=True)
+        logit_s = logit_s.float()
+        logit_t = logit_t.float()
+
+        loss_cls = criterion_cls(logit_s, labels)
+        loss_div = criterion_div(logit_s, logit_t)
+
+        if opt.distill == "kd":
+            loss_kd = 0
+        elif opt.distill == "moma":
+            student = _unwrap(model_s)
+            if ema_ok is None:
+                ema_ok = _same_arch(student, model_t)
+                if not ema_ok and getattr(opt, "rank", 0) == 0:
+                    # the reference raises half-way through the zip; defined behaviour here:
+                    print("[moma] student/teacher architectures differ: teacher stays frozen (no EMA)")
+            if ema_ok:
+                trainer.momentum_update(student, model_t, opt.alpha)                     # K4 (:309)
+                if opt.head == "mlp":
+                    criterion_kd.embed_t.eval()
+                    if _same_arch(criterion_kd.embed_s, criterion_kd.embed_t):
+                        trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
+            model_t.apply(_set_bn_train)                                                  # (:314-318)
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+                k, all_k = trainer._shuffle_bn(images, model_t, model_ema_head=criterion_kd.embed_t)   # (:320)
+                f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
+            f_s, k, all_k = f_s.float(), k.float(), all_k.float()
+
+            if opt.attn == "self":                                                        # K1 (:326-329)
+                f_s = criterion_kd.atts_q(f_s)
+                with torch.no_grad():
+                    k = criterion_kd.atts_k(k)
+                    all_k = criterion_kd.atts_queue(all_k)
+
+            if fused:                                                                     # K2 + K3
+                loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k)
+            else:                                                                         # reference sequence (:331-335)
+                criterion = nn.CrossEntropyLoss()
+                output = contrast(q=f_s, k=k, all_k=all_k)
+                c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1],
+                                                             criterion=criterion)
+                loss_kd = c_losses[0]
+        else:
+            raise NotImplementedError(opt.distill)
+
+        loss = opt.cls * loss_cls + opt.div * loss_div + opt.beta * loss_kd
+        losses.update(loss.detach(), images.size(0))
+        if trace is not None:           # optional per-step record (tests / benchmarking), device tensors
+            trace.append((loss.detach(), contrast.index if contrast is not None else None))
+
+        # =================== metrics =====================
+        top1.update(accuracy(logit_s, labels, topk=(1,))[0].squeeze(0), images.size(0))
+
+        # =================== backward =====================
+        optimizer.zero_grad(set_to_none=True)
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
+            if kd_params is None:
+                kd_params = [p for p in criterion_kd.parameters() if p.requires_grad]
+            trainer.allreduce_grads(kd_params)          # atts_q / embed_s are not under DDP (fixes Q7)
+        if scaler is not None:
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
+
+        batch_time.update(time.time() - end)
+        end = time.time()
+
+        if idx % opt.print_freq == 0:
+            print("Epoch: [{0}][{1}/{2}]\tGPU {3}\tTime: {bt:.3f}\tLoss {loss:.4f}\tAcc@1 {acc:.3f}".format(
+                epoch, idx, n_batch, opt.gpu, bt=batch_time.avg, loss=float(losses.avg), acc=float(top1.avg)))
+            sys.stdout.flush()
+    return float(top1.avg), float(losses.avg)
+
+
+def validate_distill(val_loader, model, criterion, opt):
+    """Evaluation of the student: (top-1 %, mean loss)   (reference :448-529, metrics only)."""
+    losses, top1 = AverageMeter(), AverageMeter()
+    model.eval()
+    dev = next(model.parameters()).device
+    with torch.no_grad():
+        for images, labels in val_loader:
+            images = images.to(dev, non_blocking=True)
+            labels = labels.to(dev, non_blocking=True)
+            output = model(images).float()
+            losses.update(criterion(output, labels).detach(), images.size(0))
+            top1.update(accuracy(output, labels, topk=(1,))[0].squeeze(0), images.size(0))
+    return float(top1.avg), float(losses.avg)

@@ -1,0 +1,62 @@
+"""Pin the CPU step oracle (oracle/step_oracle.py) against the 10-step trace captured from the reference's
+own train_distill_moma (tests/golden/g5_step_trace.npz): loss per step, queue pointer (bit exact), queue
+contents, grad=None on atts_k / atts_queue, final weights.  This is BASELINE.json configs[0]-style plumbing
+(CIFAR-shaped inputs, B=8, CPU), with a same-arch resnet8 pair so the reference's zip-EMA is defined."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.step_oracle import OracleCMO, OracleMoCo, StepOracle
+from moma_amd.backbones.resnet_cifar import resnet8
+
+
+def _sd(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_step_trace_matches_reference(golden_dir, ci):
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, "g5_step_trace.npz"))
+    p = f"c{ci}_"
+    head = str(g[p + "head"])
+    feat_dim = 64 if head == "None" else 32
+    ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
+    ms.load_state_dict(_sd(g, p + "s."))
+    mt.load_state_dict(_sd(g, p + "t."))
+    cmo = OracleCMO(head, 64, 64, feat_dim)
+    cmo.load_state_dict(_sd(g, p + "kd."))
+    contrast = OracleMoCo(feat_dim, 64, 0.15)
+    contrast.memory.copy_(torch.from_numpy(g[p + "memory0"]))
+    run = StepOracle(ms, mt, cmo, contrast, head=head)
+
+    gen = torch.Generator().manual_seed(int(g[p + "data_seed"]))
+    images = torch.randn(10, 8, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 100, (10, 8), generator=gen)
+    assert abs(images.double().sum().item() - float(g[p + "images_sum"])) < 1e-6, "torch RNG stream changed"
+    assert np.array_equal(labels.numpy(), g[p + "labels"])
+
+    torch.manual_seed(int(g[p + "loop_seed"]))
+    losses, accs, idxs, memsums = [], [], [], []
+    for ep in range(2):
+        run.start_epoch()
+        for i in range(5):
+            s = ep * 5 + i
+            loss, acc, _ = run.step(images[s], labels[s])
+            losses.append(loss); accs.append(acc)
+            idxs.append(contrast.index); memsums.append(contrast.memory.double().sum().item())
+    assert idxs == [int(v) for v in g[p + "index"]]                      # pointer: bit exact
+    np.testing.assert_allclose(losses, g[p + "loss"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(accs, g[p + "acc"], atol=1e-4)
+    np.testing.assert_allclose(memsums, g[p + "memsum"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(contrast.memory.numpy(), g[p + "memory_final"], rtol=1e-4, atol=1e-5)
+    assert bool(g[p + "atts_k_grad_none"]) and all(q.grad is None for q in cmo.atts_k.parameters())
+    assert bool(g[p + "atts_queue_grad_none"]) and all(q.grad is None for q in cmo.atts_queue.parameters())
+    np.testing.assert_allclose(ms.fc.weight.detach().numpy(), g[p + "s_final.fc.weight"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mt.fc.weight.detach().numpy(), g[p + "t_final.fc.weight"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(cmo.atts_q.proj.weight.detach().numpy(), g[p + "kd_final.atts_q.proj.weight"],
+                               rtol=1e-4, atol=1e-5)
+    # atts_k is in the optimizer but never gets a gradient -> not even weight decay touches it
+    assert np.array_equal(cmo.atts_k.proj.weight.detach().numpy(), g[p + "kd_final.atts_k.proj.weight"])
