@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the MoMA train step (EffNet-B0 pair, 224 px, K=65536) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of helper/loops_moma.py's moma branch over one synthetic batch: student fwd,
+teacher fwd x2 (Q8), CE + KL, multi-tensor EMA (K4), Shuffle-BN key encoding, heads, batch-token attention
+x3 (K1), one-pass InfoNCE over the K x d queue (K2), ring enqueue (K3), backward, SGD step (and, for N>1,
+the RCCL gradient all-reduce).  Inputs are resident in HBM before the timed region.  Weak scaling: per-rank
+batch fixed, per-rank queue, no data-path collective besides the gradient all-reduce.
+
+Rank 0 prints ONE JSON line with the driver's contract plus
+  "roofline"     : the dominant hand-written kernel (K2, one-pass InfoNCE) -- algorithmic bytes/flops per
+                   launch over its HIP-event-measured mean duration inside the timed region;
+  "cpu_baseline" : the CPU restatement of the same step (oracle/step_oracle.py, pinned to the reference's
+                   trace) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--batch_size", type=int, default=256, help="per-rank batch")
+    p.add_argument("--image_size", type=int, default=224)
+    p.add_argument("--nce_k", type=int, default=65536)
+    p.add_argument("--head", default="mlp", choices=["None", "linear", "mlp"])
+    p.add_argument("--feat_dim", type=int, default=512)
+    p.add_argument("--model", default="effiB0")
+    p.add_argument("--n_cls", type=int, default=4)
+    p.add_argument("--moma_prec", default="bf16", choices=["fp32", "bf16"])
+    p.add_argument("--queue_dtype", default="bf16", choices=["fp32", "bf16"])
+    p.add_argument("--amp", default="bf16", choices=["none", "bf16", "fp16"])
+    p.add_argument("--channels_last", action="store_true",
+                   help="NHWC backbones (MIOpen's depthwise backward is ~7x slower in NHWC on gfx950: off by default)")
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--cpu_batch", type=int, default=16)
+    p.add_argument("--cpu_steps", type=int, default=3)
+    p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
+    return p.parse_args()
+
+
+class EventRecorder:
+    """HIP events on the current stream around named C-ABI calls (moma_amd.ops.set_event_recorder)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def __call__(self, name):
+        rec = self
+
+        class Ctx:
+            def __enter__(self_inner):
+                if rec.enabled:
+                    self_inner.e0 = torch.cuda.Event(enable_timing=True)
+                    self_inner.e1 = torch.cuda.Event(enable_timing=True)
+                    self_inner.e0.record()
+                return self_inner
+
+            def __exit__(self_inner, *a):
+                if rec.enabled:
+                    self_inner.e1.record()
+                    rec.events.setdefault(name, []).append((self_inner.e0, self_inner.e1))
+                return False
+        return Ctx()
+
+    def mean_ms(self, name):
+        ev = self.events.get(name, [])
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def k2_algorithmic(B, d, K, qbytes):
+    """one queue read + q,k in + dq out + lse/loss/top1; flops = scores + P.Keys."""
+    bytes_ = K * d * qbytes + 3 * B * d * 4 + B * d * 4 + 12 * B
+    flops = 4.0 * B * d * (K + 1)
+    return bytes_, flops
+
+
+def make_opt(a, rank, world):
+    return argparse.Namespace(
+        distill="moma", head=a.head, feat_dim=a.feat_dim, attn="self", mem="MoCo", nce_k=a.nce_k, nce_t=0.15,
+        alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=int(os.environ.get("LOCAL_RANK", 0)),
+        multiprocessing_distributed=world > 1, print_freq=10 ** 9, batch_size=a.batch_size, rank=rank,
+        world_size=world, model_s=a.model, model_t=a.model, std_pre=None, tec_pre=None, path_t=None,
+        std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
+        learning_rate=0.05, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
+        amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
+        shuffle_bn="per_rank", num_heads=4)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use (affinity mask and cgroup quota, not the host's total)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(a):
+    """Time the CPU restatement of the same step on a bounded sample (smaller batch, few steps)."""
+    from oracle.step_oracle import OracleCMO, OracleMoCo, StepOracle
+    from moma_amd.backbones import model_dict
+    cores = min(host_cores(), 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(12345)
+    ms, mt = model_dict[a.model](num_classes=a.n_cls), model_dict[a.model](num_classes=a.n_cls)
+    s_dim = 1280 if a.model == "effiB0" else None
+    if s_dim is None:
+        with torch.no_grad():
+            s_dim = ms.eval()(torch.randn(2, 3, 64, 64), is_feat=True)[0][-1].shape[1]
+    feat_dim = s_dim if a.head == "None" else a.feat_dim
+    cmo = OracleCMO(a.head, s_dim, s_dim, feat_dim)
+    contrast = OracleMoCo(feat_dim, a.nce_k, 0.15)
+    run = StepOracle(ms, mt, cmo, contrast, head=a.head)
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(a.cpu_batch, 3, a.image_size, a.image_size, generator=g)
+    y = torch.randint(0, a.n_cls, (a.cpu_batch,), generator=g)
+    run.start_epoch()
+    run.step(x, y)                                   # warm-up (allocator, thread pool)
+    t0 = time.time()
+    for _ in range(a.cpu_steps):
+        run.step(x, y)
+    dt = time.time() - t0
+    return {"value": round(a.cpu_batch * a.cpu_steps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/step_oracle.py (reference op order, fp32), {a.model} pair {a.image_size}px, "
+                      f"B={a.cpu_batch}, K={a.nce_k}, d={feat_dim}, {a.cpu_steps} timed steps after 1 warm-up "
+                      f"({dt:.1f} s)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MoMA hot path is a HIP library (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl")              # RCCL over xGMI
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+
+    from moma_amd import ops
+    from moma_amd.train_student_moma import build_training
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.dataset.synthetic import SyntheticLoader
+
+    opt = make_opt(a, rank, world)
+    torch.manual_seed(12345)                         # identical initial weights on every rank
+    model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
+    trainer = ContrastTrainer(opt)
+    if world > 1:
+        ddp_s = nn.parallel.DistributedDataParallel(model_s, device_ids=[local], gradient_as_bucket_view=True)
+        module_list = [ddp_s] + list(module_list)[1:]
+    rec = EventRecorder()
+    ops.set_event_recorder(rec)
+
+    loader_w = SyntheticLoader(a.warmup, a.batch_size, a.image_size, a.n_cls, 12345 + rank, dev)
+    loader_t = SyntheticLoader(a.steps, a.batch_size, a.image_size, a.n_cls, 12345 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: model + queue built; warm-up {a.warmup} steps (first step JIT-compiles MIOpen kernels)")
+    if a.warmup > 0:
+        train_distill_moma(0, loader_w, module_list, criterion_list, trainer, contrast, optimizer, opt)
+    barrier()
+    log(f"warm-up done; timing {a.steps} steps")
+    rec.enabled = True
+    t0 = time.perf_counter()
+    train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
+    barrier()
+    dt = time.perf_counter() - t0
+    rec.enabled = False
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        d = contrast.memory.shape[1]
+        qbytes = contrast.memory.element_size()
+        k2_ms = rec.mean_ms("moma_infonce_fused")
+        bytes_, flops = k2_algorithmic(a.batch_size, d, a.nce_k, qbytes)
+        # governing bound = the larger ideal time: HBM for a 4-byte queue, MFMA for bf16 at B=256
+        t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+        if a.moma_prec == "bf16" and t_mfma > t_hbm:
+            ach = flops / (k2_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            ach = bytes_ / (k2_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof.update({"kernel": "moma_infonce_fused (K2 one-pass InfoNCE)", "ms_per_launch": round(k2_ms, 4),
+                     "algorithmic_bytes": bytes_, "algorithmic_flops": flops,
+                     "hbm_frac": round(bytes_ / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "mfma_frac": round(flops / (k2_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "other_ms": {k: round(rec.mean_ms(k), 4) for k in rec.events if k != "moma_infonce_fused"}})
+        out = {
+            "metric": "images/sec MoMA train step (EffNet-B0 224px, K=65536)",
+            "value": round(world * a.batch_size * a.steps / dt, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {a.model} student+teacher (random init), synthetic "
+                                   f"{a.image_size}x{a.image_size} RGB, per-GPU batch {a.batch_size}, queue K={a.nce_k} "
+                                   f"x d={d} ({a.queue_dtype}), head={a.head}, attn=self (4 heads), -c 1 -d 1 -b 1, "
+                                   f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp}, KD kernels {a.moma_prec}",
+                       "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank"},
+            "roofline": roof,
+        }
+        log(f"timed region: {dt:.2f} s; {out['value']} images/sec")
+        if world == 1 and not a.no_cpu_baseline:
+            log("timing the CPU restatement (bounded sample) ...")
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

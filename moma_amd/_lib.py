@@ -49,6 +49,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64.so.7; it must be the HIP runtime of the process (streams and
+    # device pointers come from torch).  Importing torch first makes the loader bind our library to it.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MomaHipError(
             f"libmoma_hip.so not found at {LIB_PATH}: build it with `python -m moma_amd.build` "

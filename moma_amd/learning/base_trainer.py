@@ -39,6 +39,9 @@ class BaseTrainer(object):
                 else:
                     dist.init_process_group(backend=a.dist_backend, init_method=a.dist_url,
                                             world_size=a.world_size, rank=a.rank)
+        if not dist.is_initialized():          # single process, no process group: nothing to set up
+            self.local_group = None
+            return
         # one group per node, used by Shuffle-BN in the reference-faithful gather mode
         groups = []
         for i in range(0, a.world_size // ngpus_per_node):

@@ -44,6 +44,42 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t
 
 
+def _dense_pair(p: torch.Tensor, e: torch.Tensor) -> None:
+    """Element-wise kernels walk the raw storage: both tensors must be dense with identical strides
+    (row-major or channels_last -- the memory format only permutes the walk order)."""
+    for t, nm in ((p, "param"), (e, "param_ema")):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise MomaHipError(f"{nm}: the MoMA hot path runs only on the GPU (HIP library). No CPU fallback exists.")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{nm}: expected float32, got {t.dtype}")
+    dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+    if not dense or p.stride() != e.stride():
+        raise ValueError("momentum_update: parameter pair must be dense with identical strides "
+                         f"(got {p.stride()} vs {e.stride()})")
+
+
+# Optional instrumentation (bench.py): a callable (name) -> context manager recording HIP events on the
+# current stream around a C-ABI call.  None in normal operation.
+_EVENT_RECORDER = None
+
+
+def set_event_recorder(rec) -> None:
+    global _EVENT_RECORDER
+    _EVENT_RECORDER = rec
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _timed(name):
+    return _EVENT_RECORDER(name) if _EVENT_RECORDER is not None else _NullCtx()
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -68,7 +104,7 @@ class EmaTable:
             if p.shape != e.shape:
                 raise RuntimeError(f"The size of tensor a {tuple(e.shape)} must match the size of tensor b "
                                    f"{tuple(p.shape)} (momentum_update needs identical architectures)")
-            _dev(p, "param"); _dev(e, "param_ema")
+            _dense_pair(p, e)
             if e.numel() == 0:
                 continue
             rows.append((e.data_ptr(), p.data_ptr(), e.numel(), first))
@@ -90,8 +126,9 @@ def ema_update_(table: EmaTable, m: float) -> None:
     lib = _lib.load()
     if table.n == 0:
         return
-    check(lib.moma_ema_multi(_ptr(table.table), table.n, table.total_blocks, float(m), float(1.0 - m), _stream()),
-          "moma_ema_multi")
+    with _timed("moma_ema_multi"):
+        check(lib.moma_ema_multi(_ptr(table.table), table.n, table.total_blocks, float(m), float(1.0 - m), _stream()),
+              "moma_ema_multi")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -170,9 +207,10 @@ class _InfoNCEFused(torch.autograd.Function):
         qd = _qdtype(queue)
         ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        check(lib.moma_infonce_fused(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
-                                     _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream()),
-              "moma_infonce_fused")
+        with _timed("moma_infonce_fused"):
+            check(lib.moma_infonce_fused(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
+                                         _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream()),
+                  "moma_infonce_fused")
         if need_grad:
             ctx.save_for_backward(dq)
         ctx.mark_non_differentiable(lse, top1)
@@ -209,8 +247,9 @@ class _MHA(torch.autograd.Function):
         qkv = torch.empty(N, 3 * d, device=dev, dtype=torch.float32)
         probs = torch.empty(H, N, N, device=dev, dtype=torch.float32)
         attn_out = torch.empty(N, d, device=dev, dtype=torch.float32)
-        check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
-                               _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
+        with _timed("moma_mha_fwd"):
+            check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
+                                   _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, w_qkv, w_proj, qkv, probs, attn_out)
         ctx.H, ctx.prec, ctx.has_bqkv = H, prec, b_qkv is not None

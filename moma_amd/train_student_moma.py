@@ -1,0 +1,285 @@
+"""`train_student_moma.py` CLI for the MoMA contrastive-distillation path on MI355X.
+
+Keeps every flag and default of the reference's argument parser (train_student_moma.py:46-131) and the
+startup order of its main_worker (:227-392: seed -> probe batch -> student, teacher -> s_dim/t_dim probe ->
+build_mem -> broadcast_memory -> CMO -> SGD over the trainable list -> DDP(model_s)), so seeds, checkpoints
+and launch lines carry over.  What differs:
+  * only `--distill moma` (and `kd`) are built -- the other criteria are out of scope;
+  * real datasets need author-local folders; `--dataset synthetic` (default when the requested dataset is not
+    available) feeds pre-generated batches of the same shape;
+  * one process per GPU either through torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) or, as in the
+    reference, `--multiprocessing-distributed` + mp.spawn; the backend string 'nccl' is RCCL on ROCm;
+  * new optional flags: --moma_prec, --queue_dtype, --amp, --channels_last, --shuffle_bn, --no_fused,
+    --steps_per_epoch, --num_heads.
+"""
+from __future__ import print_function
+
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .MoMA.mem_moco import build_mem
+from .MoMA.criterion_moco_att import CMO
+from .dataset.synthetic import SyntheticLoader
+from .distiller_zoo import DistillKL
+from .helper.loops_moma import train_distill_moma, validate_distill
+from .helper.util import adjust_learning_rate, reduce_tensor, save_dict_to_json
+from .learning.contrast_trainer import ContrastTrainer
+from .model_def import load_model
+from .backbones import model_dict
+
+N_CLS = {"cifar100": 100, "imagenet": 1000, "colon_tma_manual": 4, "panda_512": 4, "prostate_hv": 4, "gastric": 8}
+IMAGE_SIZE = {"cifar100": 32, "imagenet": 224}
+
+
+def build_parser():
+    p = argparse.ArgumentParser("argument for training")
+    # basic
+    p.add_argument("--print_freq", type=int, default=50, help="print frequency")
+    p.add_argument("--batch_size", type=int, default=64, help="batch_size")
+    p.add_argument("--num_workers", type=int, default=8, help="num of workers to use")
+    p.add_argument("--epochs", type=int, default=60, help="number of training epochs")
+    p.add_argument("--gpu_id", type=str, default="0", help="id(s) for CUDA_VISIBLE_DEVICES")
+    p.add_argument("--seed", default=12345, type=int, help="seed for initializing training")
+    # optimization
+    p.add_argument("--learning_rate", type=float, default=0.05)
+    p.add_argument("--lr_decay_epochs", type=str, default="30,40,60")
+    p.add_argument("--lr_decay_rate", type=float, default=0.1)
+    p.add_argument("--weight_decay", type=float, default=1e-4)
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--cosine", action="store_true")
+    # dataset and model
+    p.add_argument("--dataset", type=str, default="prostate_hv")
+    p.add_argument("--model_s", type=str, default="effiB0", choices=sorted(model_dict))
+    p.add_argument("--model_t", type=str, default="effiB0")
+    p.add_argument("--path_t", type=str, default=None, help="teacher model snapshot")
+    # augment
+    p.add_argument("--aug_train", type=str, default="RA", choices=["NULL", "RA"])
+    p.add_argument("--crop", type=float, default=0.2)
+    p.add_argument("--image_size", type=int, default=512)
+    p.add_argument("--image_resize", action="store_true")
+    p.add_argument("--n_cls", type=int, default=8)
+    p.add_argument("--skip_test", action="store_true")
+    # distillation
+    p.add_argument("--trial", type=str, default="1")
+    p.add_argument("--kd_T", type=float, default=4)
+    p.add_argument("--distill", type=str, default="kd")
+    p.add_argument("-c", "--cls", type=float, default=1.0)
+    p.add_argument("-d", "--div", type=float, default=1.0)
+    p.add_argument("-b", "--beta", type=float, default=0.0)
+    p.add_argument("-f", "--factor", type=int, default=2)
+    p.add_argument("-s", "--soft", type=float, default=1.0)
+    p.add_argument("--hint_layer", default=1, type=int, choices=[0, 1, 2, 3, 4])
+    # NCE distillation
+    p.add_argument("--feat_dim", default=512, type=int)
+    p.add_argument("--mode", default="exact", type=str, choices=["exact", "relax"])
+    p.add_argument("--nce_k", default=16384, type=int)
+    p.add_argument("--nce_t", default=0.07, type=float)
+    p.add_argument("--nce_m", default=0.5, type=float)
+    p.add_argument("--alpha", default=0.999, type=float)
+    p.add_argument("--mem", default="MoCo", type=str, choices=["MoCo", "MoCoST", "MoCoSSTT"])
+    p.add_argument("--head", default="None", type=str, choices=["None", "linear", "mlp"])
+    # distill option
+    p.add_argument("--weight", type=float, default=1e-4)
+    p.add_argument("--std_pre", type=str, default="PANDA")
+    p.add_argument("--std_strict", action="store_false", help="strict by default")
+    p.add_argument("--tec_pre", type=str, default="ImageNet")
+    p.add_argument("--tec_strict", action="store_false", help="strict by default")
+    p.add_argument("--attn", type=str, default="self")
+    # multiprocessing
+    p.add_argument("--dali", type=str, choices=["cpu", "gpu"], default=None)
+    p.add_argument("--multiprocessing-distributed", action="store_true")
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:23451", type=str)
+    p.add_argument("--deterministic", action="store_false")
+    p.add_argument("--skip_validation", action="store_false")
+    # ---- additions of this implementation ----
+    p.add_argument("--moma_prec", default="bf16", choices=["fp32", "bf16"],
+                   help="arithmetic of the KD kernels: fp32 = reference arithmetic, bf16 = bf16 MFMA / fp32 accumulate")
+    p.add_argument("--queue_dtype", default="fp32", choices=["fp32", "bf16"], help="storage of the K x d queue")
+    p.add_argument("--amp", default=None, choices=["bf16", "fp16"], help="autocast dtype for the backbones")
+    p.add_argument("--channels_last", action="store_true")
+    p.add_argument("--shuffle_bn", default="per_rank", choices=["per_rank", "gather"])
+    p.add_argument("--no_fused", action="store_true", help="reference call sequence on materialised logits")
+    p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic loader length")
+    p.add_argument("--num_heads", type=int, default=4)
+    p.add_argument("--save_root", type=str, default="./save")
+    return p
+
+
+def parse_option(argv=None):
+    opt = build_parser().parse_args(argv)
+    if opt.distill == "moma":
+        opt.nce_t = 0.15                                        # reference :135-136
+    opt.moma_fused = not opt.no_fused
+    opt.lr_decay_epochs = [int(it) for it in opt.lr_decay_epochs.split(",")]
+    ngpu = torch.cuda.device_count()
+    opt.model_path = os.path.join(
+        opt.save_root, f"kd_{opt.dataset}_{opt.model_s}_StdPre_{opt.std_pre}_and_TecPre_{opt.tec_pre}"
+                       f"_CPU{opt.num_workers}_GPU{ngpu}/")
+    opt.tb_path = os.path.join(opt.save_root, "students/")
+    name = (f"{opt.distill}_{opt.dataset}_{opt.model_s}_BS{opt.batch_size}_lr_{opt.learning_rate}_decay"
+            f"_{opt.weight_decay}_seed{opt.seed}_imageS_{opt.image_size}_cosine_{opt.cosine}"
+            f"_StdPre_{opt.std_pre}_strict_{opt.std_strict}_and_TecPre_{opt.tec_pre}_strict_{opt.tec_strict}"
+            f"_TB0_SB0_BZ64_attn_{opt.attn}")
+    if opt.distill == "moma":
+        name = f"{name}_{opt.mem}_head_{opt.head}_{opt.feat_dim}"
+    opt.model_name = f"{name}_c{opt.cls}_d{opt.div}_b{opt.beta}_trial_{opt.trial}"
+    opt.tb_folder = os.path.join(opt.tb_path, opt.model_name)
+    opt.save_folder = os.path.join(opt.model_path, opt.model_name)
+    return opt
+
+
+def build_training(opt, device):
+    """Models, criteria, queue, optimizer in the reference's construction (and RNG) order (:263-392).
+    Returns (model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer)."""
+    size = IMAGE_SIZE.get(opt.dataset, opt.image_size)
+    data = torch.randn(2, 3, size, size)                         # consumes RNG before model init (:263-268)
+    model_s = load_model(opt.model_s, opt.std_pre, opt.n_cls, opt.std_strict, opt.gpu, opt.multiprocessing_distributed)
+    model_t = load_model(opt.model_t, opt.path_t or opt.tec_pre, opt.n_cls, opt.tec_strict, opt.gpu,
+                         opt.multiprocessing_distributed)
+    model_t.eval(); model_s.eval()
+    with torch.no_grad():                                        # probe (:274-277) on a small crop to read dims
+        probe = data[:, :, :min(size, 64), :min(size, 64)]
+        feat_t, _ = model_t(probe, is_feat=True)
+        feat_s, _ = model_s(probe, is_feat=True)
+    module_list = nn.ModuleList([model_s])
+    trainable_list = nn.ModuleList([model_s])
+    criterion_cls = nn.CrossEntropyLoss()
+    criterion_div = DistillKL(opt.kd_T)
+    contrast = None
+    if opt.distill == "kd":
+        criterion_kd = DistillKL(opt.kd_T)
+    elif opt.distill == "moma":
+        opt.s_dim = feat_s[-1].shape[1]
+        opt.t_dim = feat_t[-1].shape[1]
+        if opt.head == "None":
+            opt.feat_dim = opt.s_dim
+        contrast = build_mem(opt).to(device)                     # randn(K,d) drawn here (:333-334)
+        criterion_kd = CMO(opt)
+        if opt.head == "mlp":
+            module_list.append(criterion_kd.embed_s)
+            module_list.append(criterion_kd.embed_t)
+            trainable_list.append(criterion_kd.embed_s)
+            criterion_kd.embed_t.eval()
+        if opt.attn == "self_mix":
+            trainable_list.append(criterion_kd.atts)
+        elif opt.attn == "dual":
+            trainable_list.append(criterion_kd.atts_p)
+            trainable_list.append(criterion_kd.atts_n)
+        elif opt.attn == "self_nomix":
+            trainable_list.append(criterion_kd.atts_q)
+            trainable_list.append(criterion_kd.atts_k)
+        else:
+            trainable_list.append(criterion_kd.atts_q)
+            trainable_list.append(criterion_kd.atts_k)
+            trainable_list.append(criterion_kd.atts_queue)
+    else:
+        raise NotImplementedError(opt.distill)
+    criterion_list = nn.ModuleList([criterion_cls, criterion_div, criterion_kd])
+    module_list.append(model_t)
+    optimizer = optim.SGD(trainable_list.parameters(), lr=opt.learning_rate, momentum=opt.momentum,
+                          weight_decay=opt.weight_decay)
+    module_list.to(device)
+    criterion_list.to(device)
+    if getattr(opt, "channels_last", False):
+        model_s.to(memory_format=torch.channels_last)
+        model_t.to(memory_format=torch.channels_last)
+    return model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer
+
+
+def main_worker(gpu, ngpus_per_node, opt):
+    opt.gpu = int(gpu)
+    opt.gpu_id = int(gpu)
+    opt.rank = int(os.environ.get("NODE_RANK", 0))
+    opt.dist_backend = "nccl"                                    # RCCL on ROCm (reference :232)
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_student_moma: no GPU visible. The MoMA hot path is a HIP library for gfx950 "
+                           "and has no CPU fallback.")
+    trainer = ContrastTrainer(opt)
+    trainer.init_ddp_environment(gpu, ngpus_per_node)
+    if opt.seed is not None:
+        random.seed(opt.seed)
+        torch.manual_seed(opt.seed)
+        np.random.seed(opt.seed)
+    torch.backends.cudnn.benchmark = not opt.deterministic or True
+    device = torch.device("cuda", opt.gpu)
+    print("opt.n_cls: ", opt.n_cls)
+
+    model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer = build_training(opt, device)
+    if contrast is not None:
+        trainer.broadcast_memory(contrast)                       # optional step: synchronize memory (:336)
+    if opt.multiprocessing_distributed:
+        ddp_s = torch.nn.parallel.DistributedDataParallel(model_s, device_ids=[opt.gpu], gradient_as_bucket_view=True)
+        module_list = [ddp_s] + [m for m in list(module_list)[1:]]
+    if opt.amp == "fp16":
+        opt._grad_scaler = torch.amp.GradScaler("cuda")
+    print("opt.batch_size", opt.batch_size)
+
+    size = IMAGE_SIZE.get(opt.dataset, opt.image_size)
+    seed = (opt.seed or 0) + opt.rank
+    train_loader = SyntheticLoader(opt.steps_per_epoch, opt.batch_size, size, opt.n_cls, seed, device)
+    val_loader = SyntheticLoader(max(1, opt.steps_per_epoch // 10), opt.batch_size, size, opt.n_cls, seed + 1, device)
+    is_main = (not opt.multiprocessing_distributed) or opt.rank % ngpus_per_node == 0
+    if is_main:
+        os.makedirs(opt.save_folder, exist_ok=True)
+        trainer.args.tb_folder = opt.tb_folder
+    best_acc, t_total = 0.0, time.time()
+    for epoch in range(1, opt.epochs + 1):
+        adjust_learning_rate(epoch, opt, optimizer)
+        print("==> training...")
+        t1 = time.time()
+        train_acc, train_loss = train_distill_moma(epoch, train_loader, module_list, criterion_list,
+                                                   trainer if opt.distill == "moma" else None, contrast, optimizer, opt)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        if opt.multiprocessing_distributed:
+            metrics = torch.tensor([train_acc, train_loss], device=device)
+            train_acc, train_loss = reduce_tensor(metrics, opt.world_size).tolist()
+        if is_main:
+            ips = opt.steps_per_epoch * opt.batch_size * max(1, getattr(opt, "world_size", 1)) / (t2 - t1)
+            print(" * Epoch {}, Acc@1 {:.3f}, Loss {:.4f}, Time {:.2f}, {:.1f} images/sec".format(
+                epoch, train_acc, train_loss, t2 - t1, ips))
+        val_acc, val_loss = validate_distill(val_loader, model_s, criterion_list[0], opt)
+        if is_main:
+            print(" ** Acc_val@1 {:.3f}".format(val_acc))
+            if val_acc > best_acc:
+                best_acc = val_acc
+                state = {"epoch": epoch, "model": model_s.state_dict(), "best_acc": best_acc,
+                         "best_acc_epoch": epoch, "optimizer": optimizer.state_dict()}
+                torch.save(state, os.path.join(opt.save_folder, "net_best_acc.pth"))
+    if is_main:
+        print("best accuracy:", best_acc)
+        save_state = {k: v for k, v in vars(opt).items() if not k.startswith("_") and k != "trace"}
+        save_state["Total params"] = sum(p.numel() for p in model_s.parameters()) / 1e6
+        save_state["Total time"] = (time.time() - t_total) / 3600.0
+        save_dict_to_json(save_state, os.path.join(opt.save_folder, "parameters.json"))
+
+
+def main(argv=None):
+    opt = parse_option(argv)
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:         # launched by torchrun: 1 process / GPU
+        opt.multiprocessing_distributed = True
+        opt.world_size = int(os.environ["WORLD_SIZE"])
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", opt.world_size))
+        main_worker(int(os.environ.get("LOCAL_RANK", 0)), n_local, opt)
+        return
+    os.environ["CUDA_VISIBLE_DEVICES"] = opt.gpu_id
+    ngpus_per_node = torch.cuda.device_count()
+    opt.ngpus_per_node = ngpus_per_node
+    if opt.multiprocessing_distributed:
+        import torch.multiprocessing as mp
+        opt.world_size = ngpus_per_node                            # single node, as the reference (:218-219)
+        mp.spawn(main_worker, nprocs=ngpus_per_node, args=(ngpus_per_node, opt))
+    else:
+        opt.world_size = 1
+        main_worker(0, ngpus_per_node, opt)
+
+
+if __name__ == "__main__":
+    main()

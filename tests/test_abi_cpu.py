@@ -5,6 +5,7 @@ import os
 import re
 
 import pytest
+import torch  # noqa: F401  (its HIP runtime must be the one our library binds to)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
