@@ -23,12 +23,16 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-import torch.nn as nn
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from moma_amd.miopen_env import use_shipped_db  # noqa: E402  (before torch: selects MIOpen's tuned solvers)
+
+use_shipped_db(tag=os.environ.get("LOCAL_RANK", "0"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
@@ -167,8 +171,21 @@ def cpu_baseline(a):
                       f"({dt:.1f} s)"}
 
 
+def heartbeat(period=60.0):
+    """Progress line on stderr every minute (MIOpen's first-step kernel compilation can be silent for minutes)."""
+    import threading
+    t0 = time.time()
+
+    def run():
+        while True:
+            time.sleep(period)
+            log(f"... still running, {time.time() - t0:.0f} s elapsed")
+    threading.Thread(target=run, daemon=True).start()
+
+
 def main():
     a = parse()
+    heartbeat()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))

@@ -19,9 +19,13 @@ import os
 import random
 import time
 
-import numpy as np
-import torch
-import torch.nn as nn
+from .miopen_env import use_shipped_db
+
+use_shipped_db(tag=os.environ.get("LOCAL_RANK", ""))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
 import torch.optim as optim
 
 from .MoMA.mem_moco import build_mem
