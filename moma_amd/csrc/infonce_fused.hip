@@ -18,11 +18,11 @@
 //   P     : exp2(X - m) in registers, packed to bf16: registers 8s..8s+7 ARE the A fragment of k-step s of
 //   P.K   : O[q, :] += P[q, keys] . K_tile  with B = keys read column-wise by ds_read_b64_tr_b16 in the
 //           permuted k order key(s,h,j) = 16s + 8(j>>2) + 4h + (j&3).
-//   The running max m is only raised when a tile would exceed it by more than 2^12 (rare); O is never
-//   rescaled in registers: on that event the accumulator is MERGED into the workgroup's partial slot in
-//   memory (slot = slot * 2^(m_slot - m) + O) and restarted from zero, which is also how the final partial is
-//   written.  Each WG leaves (m, l, max, O) per query row; a small combine kernel merges the chunks, adds the
-//   positive logit (exact fp32) and writes loss / lse / top-1 / dq.
+//   The softmax reference m of a wave is FIXED to the row max of its chunk's first tile (bf16 and fp32 share
+//   the exponent range, so P may exceed 1 without losing precision) and O is never rescaled; should a later
+//   tile exceed m by more than 2^64 the wave redoes its chunk in a second pass with the true chunk max.
+//   Each WG leaves (m, l, max, O) per query row; a small combine kernel merges the chunks, adds the positive
+//   logit (exact fp32) and writes loss / lse / top-1 / dq.
 //
 // LDS image of a key tile: D/128 segments of [32 keys][128 cols] with 256-B rows,
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
@@ -35,40 +35,82 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 constexpr int QROWS_WG = 128;        // query rows per workgroup (4 waves x 32)
 constexpr int KT = 32;               // keys per tile
+constexpr int NBUF = 4;              // LDS ring: tile t is consumed while t+1..t+3 are in flight (LDS-DMA)
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_THR = 12.0f; // log2 units: P <= 2^12 before the reference max is raised
+constexpr float OVERFLOW_THR = 64.0f; // log2 units: P <= 2^64 relative to the fixed reference max
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// LDS-DMA of one key tile (32 keys x D bf16) into `buf`: D/16 pieces of 1 KiB (4 rows x 256 B of one segment);
+// wave w issues pieces w, w+4, ... (PPW = D/64 per wave).  `dma_piece` issues this wave's i-th piece so that the
+// issue cost (tens of cycles each) can be spread between MFMAs instead of stalling the wave at the tile top.
+// The per-lane source offsets are recomputed from an opaque copy of the lane id at every call: hoisted out of
+// the tile loop they would occupy VGPRs for the whole kernel.
+template <int D>
+__device__ __forceinline__ void dma_piece(int i, const bf16_raw* __restrict__ queue, long key0, int K, char* buf,
+                                          int wave, int lane) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int rl = ln >> 4, slot = ln & 15;
+    const char* tile = reinterpret_cast<const char*>(queue) + key0 * (long)(D * 2);   // wave-uniform
+    const int last = (int)min((long)(KT - 1), (long)K - 1 - key0);                    // clamp rows past K (masked later)
+    const int pc = i * 4 + wave;                // wave-uniform
+    const int seg = pc >> 3, rg = pc & 7;
+    const int row = rg * 4 + rl;
+    const int ch = slot ^ swz(row);
+    const unsigned off = (unsigned)min(row, last) * (unsigned)(D * 2) + seg * 256 + ch * 16;
+    char* dst = buf + seg * 8192 + rg * 1024;   // wave-uniform LDS base; lane L lands at +16*L
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + off),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
 
 template <int D>
 __device__ __forceinline__ void dma_tile(const bf16_raw* __restrict__ queue, long key0, int K, char* buf, int wave,
                                          int lane) {
-    // tile = D/16 pieces of 1 KiB (4 rows x 256 B of one segment); wave w issues pieces w, w+4, ...
-    constexpr int NPIECE = D / 16;
-    const int rl = lane >> 4, slot = lane & 15;
 #pragma unroll
-    for (int i = 0; i < NPIECE / 4; ++i) {
-        const int pc = i * 4 + wave;            // wave-uniform
-        const int seg = pc >> 3, rg = pc & 7;
-        const int row = rg * 4 + rl;
-        long key = key0 + row;
-        if (key >= K) key = K - 1;              // clamp (masked in the softmax)
-        const int ch = slot ^ swz(row);
-        const char* src = reinterpret_cast<const char*>(queue) + key * (long)(D * 2) + seg * 256 + ch * 16;
-        char* dst = buf + seg * 8192 + rg * 1024;   // wave-uniform LDS base; lane L lands at +16*L
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
+    for (int i = 0; i < D / 64; ++i) dma_piece<D>(i, queue, key0, K, buf, wave, lane);
 }
 
-template <int D, bool WITH_DQ>
-__global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const float* __restrict__ q,
-                                                               const bf16_raw* __restrict__ queue, int B, int K,
-                                                               float scale_log2, int nbt, int nchunk,
-                                                               int tiles_per_chunk, int Bpad,
-                                                               float* __restrict__ o_part, float* __restrict__ m_part,
-                                                               float* __restrict__ l_part, float* __restrict__ x_part) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Q operand pre-pack: scale by log2(e)/T, round to bf16 and store in MFMA-fragment order so that every
+// workgroup of the main kernel fetches its Q tile with fully coalesced 16-B-per-lane loads:
+//   qpack[((row_tile*KS + ks)*64 + lane)] = 8 bf16 = Q[32*row_tile + (lane&31)][16*ks + 8*(lane>>5) + 0..7]
+// (rows >= B are zero).  One 64-lane "virtual wave" per 32-row tile.
+template <int D>
+__global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restrict__ q, int B, float scale_log2,
+                                                            uint4* __restrict__ qpack, int n_row_tiles,
+                                                            int* __restrict__ any_ovf) {
+    constexpr int KS = D / 16;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *any_ovf = 0;     // re-armed every call (graph-replay safe)
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);          // (row tile, k-step)
+    if (item >= n_row_tiles * KS) return;
+    const int rt = item / KS, ks = item % KS;
+    const int row = rt * 32 + (lane & 31), h = lane >> 5;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < B) {
+        const float* qp = q + (long)row * D + 16 * ks + 8 * h;
+        a = *reinterpret_cast<const float4*>(qp);
+        b = *reinterpret_cast<const float4*>(qp + 4);
+    }
+    const bf16x8 f = bf16x8{(__bf16)(a.x * scale_log2), (__bf16)(a.y * scale_log2), (__bf16)(a.z * scale_log2),
+                            (__bf16)(a.w * scale_log2), (__bf16)(b.x * scale_log2), (__bf16)(b.y * scale_log2),
+                            (__bf16)(b.z * scale_log2), (__bf16)(b.w * scale_log2)};
+    qpack[(long)item * 64 + lane] = __builtin_bit_cast(uint4, f);
+}
+
+// REPAIR = false: first (normally only) launch.  The softmax reference m of a wave is FIXED to the row max of
+//   its chunk's first tile: bf16 and fp32 share the 8-bit exponent, so P = 2^(x - m) may exceed 1 by many
+//   orders of magnitude without losing precision and O is never rescaled.  A wave that meets a score more than
+//   2^OVERFLOW_THR above m raises flag[chunk][wave-of-rows]; its partials are then invalid.
+// REPAIR = true : second launch of the same grid; workgroups without a raised flag exit at once, flagged
+//   waves redo their chunk with m = the true chunk max the first launch recorded (x_part) -- cannot overflow.
+template <int D, bool WITH_DQ, bool REPAIR>
+__device__ __forceinline__ void infonce_flash_body(const int id, char* smem, const uint4* __restrict__ qpack,
+                                                   const bf16_raw* __restrict__ queue, int B, int K, int nbt,
+                                                   int nchunk, int tiles_per_chunk, int Bpad,
+                                                   unsigned* __restrict__ o_part, float* __restrict__ m_part,
+                                                   float* __restrict__ l_part, float* __restrict__ x_part,
+                                                   int* __restrict__ ovf_flag) {
     constexpr int KS = D / 16;       // k-steps of the score product
     constexpr int NCT = D / 32;      // 32-column tiles of O
     constexpr int TILE_BYTES = KT * D * 2;
@@ -80,7 +122,6 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const float* __re
     // block -> (query tile, key chunk): the nbt tiles of one chunk are 8 block ids apart (same XCD)
     int bt, chunk;
     {
-        const int id = blockIdx.x;
         if ((nchunk & 7) == 0) {
             const int g = id / (8 * nbt), r = id % (8 * nbt);
             bt = r >> 3;
@@ -93,24 +134,26 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const float* __re
     const int ntiles = (K + KT - 1) / KT;
     const int t0 = chunk * tiles_per_chunk;
     const int t1 = min(t0 + tiles_per_chunk, ntiles);
-    const int qrow = bt * QROWS_WG + wave * 32 + n;      // the query this lane carries in the score layout
+    // partial slot of this wave's 32 query rows in chunk `chunk`
+    const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
+    int* my_flag = ovf_flag + ((long)chunk * nbt + bt) * 4;      // 4 ints per workgroup, one per wave
 
-    // ---- Q fragments: B operand of X = K.Q^T ; lane (q=n, h) holds Q[q][16ks + 8h + j], pre-scaled by log2e/T
+    bool active = true;
+    float m_ref = NEG_BIG;
+    if constexpr (REPAIR) {
+        const int f0 = my_flag[0], f1 = my_flag[1], f2 = my_flag[2], f3 = my_flag[3];
+        if ((f0 | f1 | f2 | f3) == 0) return;                    // workgroup-uniform
+        active = my_flag[wave] != 0;                             // wave-uniform
+        m_ref = x_part[prow + n];
+    }
+
+    // ---- Q fragments: B operand of X = K.Q^T ; lane (q=n, h) holds Q[q][16ks + 8h + j], pre-scaled by log2e/T,
+    //      pre-packed in fragment order by infonce_qpack_kernel (coalesced 16 B per lane)
     bf16x8 qf[KS];
     {
-        const bool ok = qrow < B;
-        const float* qp = q + (long)(ok ? qrow : 0) * D + 8 * h;
+        const uint4* qp = qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (ok) {
-                a = *reinterpret_cast<const float4*>(qp + 16 * ks);
-                b = *reinterpret_cast<const float4*>(qp + 16 * ks + 4);
-            }
-            qf[ks] = bf16x8{(__bf16)(a.x * scale_log2), (__bf16)(a.y * scale_log2), (__bf16)(a.z * scale_log2),
-                            (__bf16)(a.w * scale_log2), (__bf16)(b.x * scale_log2), (__bf16)(b.y * scale_log2),
-                            (__bf16)(b.z * scale_log2), (__bf16)(b.w * scale_log2)};
-        }
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qp[ks * 64]);
     }
 
     f32x16 O[WITH_DQ ? NCT : 1];
@@ -120,7 +163,8 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
     }
-    float m_run = NEG_BIG, l_run = 0.f, mx = NEG_BIG;
+    float l_run = 0.f, mx = NEG_BIG;
+    int ovf = 0;
 
     // per-lane LDS offsets
     //  row read (A operand of the score MFMA): key row n, chunk 2*(ks&7)+h of segment ks>>3
@@ -142,164 +186,203 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const float* __re
             for (int u = 0; u < 2; ++u) b_off[c][u] = base + (((((c ^ q4) << 2) | (e ^ (2 * u)))) << 4);
     }
 
-    // partial slot of this wave's 32 query rows in chunk `chunk`
-    const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
-    bool o_dirty = false;        // O holds un-flushed contributions
-    bool slot_used = false;      // the slot already holds a flushed accumulator (relative to m_slot)
-    float m_slot = NEG_BIG;
-    auto merge_store = [&](float m_ref) {
-        // slot = slot * 2^(m_slot - m_ref) + O ; O = 0.  O carries the query on registers / lane half.
-        if constexpr (WITH_DQ) {
-            if (slot_used) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const float a_q = __builtin_amdgcn_exp2f(m_slot - m_ref);
-                float av[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) av[r] = __shfl(a_q, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* dst = o_part + (prow + (r & 3) + 8 * (r >> 2) + 4 * h) * D + c * 32 + n;
-                        *dst = fmaf(*dst, av[r], O[c][r]);
-                        O[c][r] = 0.f;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        o_part[(prow + (r & 3) + 8 * (r >> 2) + 4 * h) * D + c * 32 + n] = O[c][r];
-                        O[c][r] = 0.f;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            slot_used = true;
-            m_slot = m_ref;
-        }
+    // LDS-DMA ring.  Every wave issues PPW pieces per tile, in tile order, so "all but the newest j tiles of
+    // this wave have landed" is s_waitcnt vmcnt(j*PPW); the workgroup barrier then makes the other waves'
+    // pieces visible too.  __syncthreads() would drain vmcnt to 0, hence the raw s_barrier.
+    constexpr int PPW = D / 64;                       // DMA instructions per wave per tile
+    auto wait_tiles_in_flight = [&](int j) __attribute__((always_inline)) {
+        if (j >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (t0 + j < t1) dma_tile<D>(queue, (long)(t0 + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+    wait_tiles_in_flight(min(t1 - t0, NBUF - 1) - 1);
+    __builtin_amdgcn_s_barrier();
 
-    if (t0 < t1) dma_tile<D>(queue, (long)t0 * KT, K, smem, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+#pragma unroll 1
     for (int t = t0; t < t1; ++t) {
-        char* buf = smem + ((t - t0) & 1) * TILE_BYTES;
-        if (t + 1 < t1) dma_tile<D>(queue, (long)(t + 1) * KT, K, smem + (((t - t0) & 1) ^ 1) * TILE_BYTES, wave, lane);
-
-        // ---- scores: X[key, q] over D ; fragments fetched one group (4 k-steps) ahead of the MFMAs that use them
-        f32x16 x;
+        char* buf = smem + ((t - t0) % NBUF) * TILE_BYTES;
+        // the ring slot every wave finished reading before the barrier that ended tile t-1 is refilled with tile
+        // t+NBUF-1; its PPW pieces are issued between the MFMA groups of the score product below
+        const bool refill = t + NBUF - 1 < t1;
+        char* rbuf = smem + ((t - t0 + NBUF - 1) % NBUF) * TILE_BYTES;
+        const long rkey0 = (long)(t + NBUF - 1) * KT;
+        if (!active && refill) dma_tile<D>(queue, rkey0, K, rbuf, wave, lane);
+        if (active) {
+            // ---- scores: X[key, q] over D ; fragments fetched one group (4 k-steps) ahead of their MFMAs
+            f32x16 x;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = 0.f;
-        {
-            constexpr int G = 4, NG = KS / G;
-            bf16x8 kf[2][G];
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-                kf[0][i] = *reinterpret_cast<const bf16x8*>(buf + (i >> 3) * 8192 + a_off[i & 7]);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
+            for (int r = 0; r < 16; ++r) x[r] = 0.f;
+            {
+                // A fragments (keys) are requested PFG groups of G k-steps ahead of the MFMAs that consume them;
+                // the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the reads behind the
+                // MFMAs and exposes the LDS latency once per group)
+                constexpr int G = 4, NG = KS / G, PFG = 2;
+                bf16x8 kf[PFG + 1][G];
+                auto rd = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
                     for (int i = 0; i < G; ++i) {
-                        const int ks = (g + 1) * G + i;
-                        kf[(g + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 3) * 8192 + a_off[ks & 7]);
+                        const int ks = g * G + i;
+                        kf[g % (PFG + 1)][i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 3) * 8192 + a_off[ks & 7]);
                     }
-                }
+                };
 #pragma unroll
-                for (int i = 0; i < G; ++i)
-                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g & 1][i], qf[g * G + i], x, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < PFG; ++g)
+                    if (g < NG) rd(g);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + PFG < NG) rd(g + PFG);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < G; ++i)
+                        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g % (PFG + 1)][i], qf[g * G + i], x, 0, 0, 0);
+                    static_assert(NG == PPW, "one DMA piece per MFMA group");
+                    if (refill) dma_piece<D>(g, queue, rkey0, K, rbuf, wave, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        // key of register r on this lane: (r&3) + 8*(r>>2) + 4*h
-        if ((t + 1) * KT > K) {
+            // key of register r on this lane: (r&3) + 8*(r>>2) + 4*h
+            if ((t + 1) * KT > K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= K) x[r] = NEG_BIG;
+                }
+            }
+            float tmax = x[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            mx = fmaxf(mx, tmax);
+            if constexpr (!REPAIR) {
+                if (t == t0) m_ref = tmax;
+                ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
+            }
+            float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (key >= K) x[r] = NEG_BIG;
+                x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);
+                psum += x[r];
             }
-        }
-        float tmax = x[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        mx = fmaxf(mx, tmax);
-        if (!__all(tmax - m_run <= RESCALE_THR)) {
-            // raise the reference max: flush what O holds (relative to the old m_run) into the partial slot
+            l_run += psum;
             if constexpr (WITH_DQ) {
-                if (o_dirty) {
-                    merge_store(m_run);
-                    o_dirty = false;
+                bf16x8 pa[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    pa[s] = bf16x8{(__bf16)x[8 * s + 0], (__bf16)x[8 * s + 1], (__bf16)x[8 * s + 2], (__bf16)x[8 * s + 3],
+                                   (__bf16)x[8 * s + 4], (__bf16)x[8 * s + 5], (__bf16)x[8 * s + 6], (__bf16)x[8 * s + 7]};
+                // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols]
+                // The transposed reads are issued as inline asm: through the builtin hipcc orders every
+                // ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the
+                // tile ring.  The asm reads are counted by hand: fragments of column tile c+PF are requested
+                // before tile c's MFMAs, so "tile c has arrived" is lgkmcnt(4*PF) (LDS returns in order).
+                constexpr int PF = 2;
+                const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
+                unsigned ba[4][2];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    ba[c4][0] = lbase + b_off[c4][0];
+                    ba[c4][1] = lbase + b_off[c4][1];
+                }
+                s16x4 kb[PF + 1][4];
+                auto issue = [&](int c) __attribute__((always_inline)) {
+                    s16x4* k4 = kb[c % (PF + 1)];
+                    const int imm = (c >> 2) * 8192;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
+                };
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+                for (int c = 0; c < PF; ++c) issue(c);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) {
+                    if (c + PF < NCT) issue(c + PF);
+                    const int ahead = (c + PF < NCT) ? PF : (NCT - 1 - c);
+                    if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    s16x4* k4 = kb[c % (PF + 1)];
+                    const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
+                    O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const float m_new = fmaxf(m_run, tmax);
-            l_run *= __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
         }
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            x[r] = __builtin_amdgcn_exp2f(x[r] - m_run);
-            psum += x[r];
-        }
-        l_run += psum;
+        // tile t+1 must have landed (tiles t+2.. may stay in flight); every wave must be done with this buffer
+        wait_tiles_in_flight(min(t + NBUF - 1, t1 - 1) - (t + 1));
+        __builtin_amdgcn_s_barrier();
+    }
 
+    // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (h == 0) {
+            m_part[prow + n] = m_ref;
+            l_part[prow + n] = l_tot;
+            if constexpr (!REPAIR) x_part[prow + n] = mx;
+        }
+        if constexpr (!REPAIR) {
+            const int any = __any(ovf) ? 1 : 0;
+            if (lane == 0) {
+                my_flag[wave] = any;
+                if (any) atomicOr(ovf_flag + (long)nchunk * nbt * 4, 1);     // global "some wave overflowed" word
+            }
+        }
         if constexpr (WITH_DQ) {
-            bf16x8 pa[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                pa[s] = bf16x8{(__bf16)x[8 * s + 0], (__bf16)x[8 * s + 1], (__bf16)x[8 * s + 2], (__bf16)x[8 * s + 3],
-                               (__bf16)x[8 * s + 4], (__bf16)x[8 * s + 5], (__bf16)x[8 * s + 6], (__bf16)x[8 * s + 7]};
-            // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols] ; column tile c+1's key fragments are fetched
-            //      while tile c's MFMAs run
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            auto ld_kb = [&](int c, int s) -> bf16x8 {
-                const char* pb = buf + (c >> 2) * 8192 + (16 * s) * 256;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(pb + b_off[c & 3][0]));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(pb + 8 * 256 + b_off[c & 3][1]));
-                const s16x8 kb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                return __builtin_bit_cast(bf16x8, kb);
-            };
-            bf16x8 kb[2][2];
-            kb[0][0] = ld_kb(0, 0);
-            kb[0][1] = ld_kb(0, 1);
+            // O partial as bf16 pairs [row][D/2]: neighbouring lanes hold neighbouring columns, so even lanes take
+            // both columns of row(r) and odd lanes both columns of row(r+1) -> one 4-byte store per lane
+            const int odd = n & 1;
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-                if (c + 1 < NCT) {
-                    kb[(c + 1) & 1][0] = ld_kb(c + 1, 0);
-                    kb[(c + 1) & 1][1] = ld_kb(c + 1, 1);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float e = O[c][r], o = O[c][r + 1];
+                    const float recv = __shfl_xor(odd ? e : o, 1, 64);
+                    const float lo = odd ? recv : e, hi = odd ? o : recv;
+                    const int rr = r + odd;
+                    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                    const unsigned pk = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                    o_part[(prow + row) * (D / 2) + c * 16 + (n >> 1)] = pk;
                 }
-                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], kb[c & 1][0], O[c], 0, 0, 0);
-                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], kb[c & 1][1], O[c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            o_dirty = true;
         }
-        // next tile's DMA must have landed, and every wave must be done reading this buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+}
 
-    // ---- partials: per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (h == 0) {
-        m_part[prow + n] = m_run;
-        l_part[prow + n] = l_tot;
-        x_part[prow + n] = mx;
+template <int D, bool WITH_DQ, bool REPAIR>
+__global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const uint4* __restrict__ qpack,
+                                                               const bf16_raw* __restrict__ queue, int B, int K,
+                                                               int nbt, int nchunk, int tiles_per_chunk, int Bpad,
+                                                               unsigned* __restrict__ o_part, float* __restrict__ m_part,
+                                                               float* __restrict__ l_part, float* __restrict__ x_part,
+                                                               int* __restrict__ ovf_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (REPAIR) {
+        // normally nothing overflowed: one word says so and the whole (small) grid leaves at once
+        if (ovf_flag[(long)nchunk * nbt * 4] == 0) return;
+        for (int id = blockIdx.x; id < nbt * nchunk; id += gridDim.x) {
+            infonce_flash_body<D, WITH_DQ, true>(id, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad, o_part,
+                                                 m_part, l_part, x_part, ovf_flag);
+            __syncthreads();
+        }
+    } else {
+        infonce_flash_body<D, WITH_DQ, false>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
+                                              o_part, m_part, l_part, x_part, ovf_flag);
     }
-    merge_store(m_run);
 }
 
 // merge the key chunks of one query row, add the positive logit (exact fp32), emit loss / lse / top-1 / dq
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                int B, int D, float inv_T, int nchunk, int Bpad,
-                                                               const float* __restrict__ o_part,
+                                                               const unsigned* __restrict__ o_part,
                                                                const float* __restrict__ m_part,
                                                                const float* __restrict__ l_part,
                                                                const float* __restrict__ x_part,
@@ -351,12 +434,54 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         top1[b] = (s0l >= X) ? 1 : 0;
     }
     if (dq != nullptr) {
+        // 4 groups of 64 threads take the chunks j = g, g+4, ...; a thread owns 8 adjacent columns (one 16-B load
+        // of bf16 per chunk, 8 loads in flight); the 4 group sums meet in LDS
+        __shared__ float accs[4][520];
         const float invL = 1.f / L;
         const float cpos = p0u * invL - 1.f;
+        const int g = tid >> 6, tg = tid & 63;
+        const int n8 = D / 8;
+        __syncthreads();                                   // wts[] complete
+        for (int c8 = tg; c8 < n8; c8 += 64) {
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = 0.f;
+            const uint4* src = reinterpret_cast<const uint4*>(o_part + (long)b * (D / 2)) + c8;
+            const long stride = (long)Bpad * (D / 8);      // uint4 per chunk
+            int j = g;
+            for (; j + 28 < nchunk; j += 32) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long)(j + 4 * u) * stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float w = wts[j + 4 * u];
+                    const unsigned vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[2 * i] = fmaf(w, __uint_as_float(vv[i] << 16), a[2 * i]);
+                        a[2 * i + 1] = fmaf(w, __uint_as_float(vv[i] & 0xffff0000u), a[2 * i + 1]);
+                    }
+                }
+            }
+            for (; j < nchunk; j += 4) {
+                const uint4 v = src[(long)j * stride];
+                const float w = wts[j];
+                const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[2 * i] = fmaf(w, __uint_as_float(vv[i] << 16), a[2 * i]);
+                    a[2 * i + 1] = fmaf(w, __uint_as_float(vv[i] & 0xffff0000u), a[2 * i + 1]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accs[g][c8 * 8 + i] = a[i];
+        }
+        __syncthreads();
         for (int c = tid; c < D; c += 256) {
-            float acc = 0.f;
-            for (int j = 0; j < nchunk; ++j) acc = fmaf(wts[j], o_part[((long)j * Bpad + b) * D + c], acc);
-            dq[(long)b * D + c] = (cpos * k[(long)b * D + c] + acc * invL) * inv_T;
+            const float acc = accs[0][c] + accs[1][c] + accs[2][c] + accs[3][c];
+            const long o = (long)b * D + c;
+            dq[o] = (cpos * k[o] + acc * invL) * inv_T;
         }
     }
 }
@@ -392,7 +517,8 @@ bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec) {
 size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
-    return (rows * d + 3 * rows) * sizeof(float) + 256;
+    return rows * d * 2 + 3 * rows * sizeof(float) + ((size_t)p.nchunk * p.nbt * 4 + 4) * sizeof(int) +
+           (size_t)p.Bpad * d * 2 + 1024;
 }
 
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
@@ -403,27 +529,41 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     float* m_part = (float*)ws;
     float* l_part = m_part + rows;
     float* x_part = l_part + rows;
-    float* o_part = x_part + rows;
+    int* flags = (int*)(x_part + rows);
+    unsigned* o_part = (unsigned*)(((uintptr_t)(flags + (size_t)p.nchunk * p.nbt * 4 + 4) + 255) & ~(uintptr_t)255);
+    uint4* qpack = (uint4*)(((uintptr_t)(o_part + rows * (d / 2)) + 255) & ~(uintptr_t)255);
     const float scale_log2 = inv_T * 1.4426950408889634f;
     const dim3 grid(p.nbt * p.nchunk), block(256);
-    const size_t lds = 2 * (size_t)KT * d * 2;
+    const dim3 rgrid(min(p.nbt * p.nchunk, 16));     // repair pass: a handful of workgroups walk the (normally empty) list
+    const size_t lds = (size_t)NBUF * KT * d * 2;
     const bf16_raw* qu = (const bf16_raw*)queue;
-#define MOMA_FLASH_LAUNCH(DD)                                                                                      \
-    do {                                                                                                           \
-        if (dq) {                                                                                                  \
-            hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, true>), grid, block, lds, st, q, qu, B, K, scale_log2, p.nbt,  \
-                               p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part);               \
-        } else {                                                                                                   \
-            hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, false>), grid, block, lds, st, q, qu, B, K, scale_log2, p.nbt, \
-                               p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part);               \
-        }                                                                                                          \
+    static bool attr_done = false;
+    if (!attr_done) {
+        const int mx = NBUF * KT * 512 * 2;
+#define MOMA_SET_LDS(DD, A, Bx) (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, A, Bx>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+        MOMA_SET_LDS(512, true, false); MOMA_SET_LDS(512, true, true); MOMA_SET_LDS(512, false, false); MOMA_SET_LDS(512, false, true);
+        MOMA_SET_LDS(384, true, false); MOMA_SET_LDS(384, true, true); MOMA_SET_LDS(384, false, false); MOMA_SET_LDS(384, false, true);
+        MOMA_SET_LDS(256, true, false); MOMA_SET_LDS(256, true, true); MOMA_SET_LDS(256, false, false); MOMA_SET_LDS(256, false, true);
+#undef MOMA_SET_LDS
+        attr_done = true;
+    }
+#define MOMA_FLASH_ARGS qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part, flags
+#define MOMA_FLASH_LAUNCH(DD)                                                                             \
+    do {                                                                                                  \
+        hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, scale_log2, qpack, p.Bpad / 32, flags + (size_t)p.nchunk * p.nbt * 4); \
+        if (dq) {                                                                                         \
+            hipLaunchKernelGGL((infonce_flash_kernel<DD, true, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
+            hipLaunchKernelGGL((infonce_flash_kernel<DD, true, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
+        } else {                                                                                          \
+            hipLaunchKernelGGL((infonce_flash_kernel<DD, false, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
+            hipLaunchKernelGGL((infonce_flash_kernel<DD, false, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
+        }                                                                                                 \
     } while (0)
     if (d == 512) MOMA_FLASH_LAUNCH(512);
     else if (d == 384) MOMA_FLASH_LAUNCH(384);
     else MOMA_FLASH_LAUNCH(256);
 #undef MOMA_FLASH_LAUNCH
+#undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(infonce_combine_kernel, dim3(B), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,

@@ -135,7 +135,10 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
 
 
 @pytest.mark.parametrize("B,d,K,qdt", [(64, 512, 4096, "fp32"), (37, 96, 1000, "fp32"), (256, 512, 8192, "bf16"),
-                                       (16, 1280, 2048, "fp32"), (1, 64, 100, "fp32")])
+                                       (16, 1280, 2048, "fp32"), (1, 64, 100, "fp32"),
+                                       # bf16 queue + bf16 MFMA -> the one-pass flash kernel (ragged B, K tails)
+                                       (100, 384, 5000, "bf16"), (300, 256, 777, "bf16"), (7, 512, 33, "bf16"),
+                                       (129, 512, 65536, "bf16")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
@@ -165,6 +168,57 @@ def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     loss_rows.sum().backward()
     scale = np.abs(ref_dq).max()
     np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=(2e-5 if prec == "fp32" else 2e-2) * scale)
+
+
+@pytest.mark.parametrize("B,d,K", [(256, 512, 4096), (100, 384, 1000), (33, 256, 300), (128, 512, 65536)])
+def test_infonce_flash_queue_term(ops, B, d, K):
+    """The sum_j p_bj * queue_j part of dq in isolation: k = 0 removes the positive-key term, and every query is
+    aligned with a few queue rows so the softmax is peaked and the weighted key sum is O(1), not averaged away."""
+    rng = np.random.default_rng(B * 7 + d + K)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    idx = rng.integers(0, K, size=(B, 3))
+    q = (queue[idx[:, 0]] * 1.6 + queue[idx[:, 1]] * 1.45 + queue[idx[:, 2]] * 1.3
+         + 0.2 * rng.standard_normal((B, d)).astype(np.float32) / np.sqrt(d)).astype(np.float32)
+    k = np.zeros((B, d), dtype=np.float32)
+    T = 0.15
+    tq = _t(q).requires_grad_(True)
+    tqueue = _t(queue, torch.bfloat16)
+    qe = tqueue.float().cpu().numpy()
+    ref_dq = O.infonce_grad(q, k, qe, T) * B
+    ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
+    loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), tqueue, T, "bf16")
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=0, atol=2e-2)
+    loss_rows.sum().backward()
+    got = tq.grad.cpu().numpy()
+    rown = np.linalg.norm(ref_dq, axis=1)
+    assert rown.min() > 0.5                       # the term under test is not negligible
+    err = np.linalg.norm(got - ref_dq, axis=1) / rown
+    assert err.max() < 2e-2, err.max()
+
+
+def test_infonce_flash_overflow_repair(ops):
+    """A key far down the chunk beats the first tile's max by > 2^64: the first launch flags the wave and the
+    repair launch redoes the chunk with the true chunk max (rule 26: force the rare branch, full reference)."""
+    rng = np.random.default_rng(7)
+    B, d, K, T = 40, 256, 3000, 0.15
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    # rows 5 and 17 see a huge logit at keys 1500 / 2999 (late tiles of their chunks): s = |q|*30/T ~ 200 nats
+    queue[1500] = 30.0 * q[5] / np.linalg.norm(q[5])
+    queue[2999] = 25.0 * q[17] / np.linalg.norm(q[17])
+    tq = _t(q).requires_grad_(True)
+    tqueue = _t(queue, torch.bfloat16)
+    qe = tqueue.float().cpu().numpy()
+    ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, qe, T) * B
+    loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), tqueue, T, "bf16")
+    # logits of ~200 nats carry a bf16 operand rounding of 2^-8 relative
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=1e-2, atol=2e-2)
+    assert np.all(np.isfinite(lse.cpu().numpy()))
+    assert abs(loss_rows.mean().item() - ref["loss"]) < 1e-2 * abs(ref["loss"])
+    loss_rows.sum().backward()
+    np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
 
 
 # ------------------------------------------------------------------------------------------------ K1
