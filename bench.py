@@ -94,6 +94,38 @@ class EventRecorder:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
 
+class KernelEvents:
+    """Raw hipEvent_t pairs handed to moma_infonce_fused_ex, which records them on the launch stream right
+    before / after the one-pass kernel (the kernel the roofline is quoted for)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")          # torch's HIP runtime, already loaded in this process
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.pairs = []
+        self.enabled = False
+
+    def __call__(self):
+        if not self.enabled:
+            return (None, None)
+        a, b = self.C.c_void_p(), self.C.c_void_p()
+        assert self.hip.hipEventCreate(self.C.byref(a)) == 0 and self.hip.hipEventCreate(self.C.byref(b)) == 0
+        self.pairs.append((a, b))
+        return (a.value, b.value)
+
+    def mean_ms(self):
+        if not self.pairs:
+            return None
+        tot = 0.0
+        for a, b in self.pairs:
+            ms = self.C.c_float()
+            assert self.hip.hipEventElapsedTime(self.C.byref(ms), a, b) == 0
+            tot += ms.value
+        return tot / len(self.pairs)
+
+
 def k2_algorithmic(B, d, K, qbytes):
     """one queue read + q,k in + dq out + lse/loss/top1; flops = scores + P.Keys."""
     bytes_ = K * d * qbytes + 3 * B * d * 4 + B * d * 4 + 12 * B
@@ -214,6 +246,8 @@ def main():
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()
     ops.set_event_recorder(rec)
+    kev = KernelEvents()
+    ops.set_kernel_event_provider(kev)
 
     loader_w = SyntheticLoader(a.warmup, a.batch_size, a.image_size, a.n_cls, 12345 + rank, dev)
     loader_t = SyntheticLoader(a.steps, a.batch_size, a.image_size, a.n_cls, 12345 + rank, dev)
@@ -224,16 +258,22 @@ def main():
         torch.cuda.synchronize()
 
     log(f"rank {rank}/{world}: model + queue built; warm-up {a.warmup} steps (first step JIT-compiles MIOpen kernels)")
+    import contextlib
+    quiet = contextlib.redirect_stdout(sys.stderr)      # stdout carries exactly one JSON line
     if a.warmup > 0:
-        train_distill_moma(0, loader_w, module_list, criterion_list, trainer, contrast, optimizer, opt)
+        with quiet:
+            train_distill_moma(0, loader_w, module_list, criterion_list, trainer, contrast, optimizer, opt)
     barrier()
     log(f"warm-up done; timing {a.steps} steps")
     rec.enabled = True
+    kev.enabled = True
     t0 = time.perf_counter()
-    train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
+    with quiet:
+        train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
     barrier()
     dt = time.perf_counter() - t0
     rec.enabled = False
+    kev.enabled = False
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -243,7 +283,8 @@ def main():
     if rank == 0:
         d = contrast.memory.shape[1]
         qbytes = contrast.memory.element_size()
-        k2_ms = rec.mean_ms("moma_infonce_fused")
+        k2_ms = kev.mean_ms()                         # the one-pass kernel alone (events recorded by the library)
+        k2_call_ms = rec.mean_ms("moma_infonce_fused")  # whole C-ABI call: q pre-pack + pass + repair check + combine
         bytes_, flops = k2_algorithmic(a.batch_size, d, a.nce_k, qbytes)
         # governing bound = the larger ideal time: HBM for a 4-byte queue, MFMA for bf16 at B=256
         t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
@@ -255,7 +296,8 @@ def main():
             ach = bytes_ / (k2_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        roof.update({"kernel": "moma_infonce_fused (K2 one-pass InfoNCE)", "ms_per_launch": round(k2_ms, 4),
+        roof.update({"kernel": "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)",
+                     "ms_per_launch": round(k2_ms, 4), "whole_call_ms": round(k2_call_ms, 4),
                      "algorithmic_bytes": bytes_, "algorithmic_flops": flops,
                      "hbm_frac": round(bytes_ / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "mfma_frac": round(flops / (k2_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -101,6 +101,13 @@ int moma_infonce_fused(const float* q, const float* k, const void* queue, int B,
                        float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
                        void* workspace, size_t workspace_bytes, int qdtype, int prec,
                        moma_stream_t stream);
+/* Same, with an optional measurement hook: ev_begin / ev_end are hipEvent_t handles (or NULL) recorded on
+ * `stream` immediately before / after the dominant kernel of the call (the one pass over the queue), so a
+ * benchmark can time exactly the kernel its roofline is quoted for.  No synchronisation is performed. */
+int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int B, int d, int K,
+                          float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
+                          void* workspace, size_t workspace_bytes, int qdtype, int prec,
+                          moma_stream_t stream, void* ev_begin, void* ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  batch-token multi-head attention -- replaces Attention.forward

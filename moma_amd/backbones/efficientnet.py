@@ -8,10 +8,18 @@ _se_expand/_project_conv/_bn0.._bn2, _conv_head, _bn1, classifier_.1) match the 
 PyTorch-ROCm / MIOpen: backbones are out of scope as kernels.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+# Which PyTorch-ROCm path the two MIOpen-weak ops take (measured on MI355X, bf16 NCHW, B=256; see DESIGN.md):
+#   depthwise convolutions: MIOpen has no tuned gfx950 solver and falls back to naive_conv_* kernels; ATen's own
+#                           depthwise kernel (used when the cudnn/MIOpen backend is switched off for the call) is faster;
+#   batch norm            : MIOpen stays the default (ATen native measured 5 % slower on the whole step).
+_DW_NATIVE = os.environ.get("MOMA_DW_NATIVE", "1") == "1"
+_BN_NATIVE = os.environ.get("MOMA_BN_NATIVE", "0") == "1"
 
 # (repeats, kernel, stride, expand, cin, cout, se_ratio) -- EfficientNet-B0 stage table
 _B0_STAGES = [
@@ -38,10 +46,24 @@ class SamePadConv2d(nn.Conv2d):
         sh, sw = self.stride
         ph = max((math.ceil(ih / sh) - 1) * sh + kh - ih, 0)
         pw = max((math.ceil(iw / sw) - 1) * sw + kw - iw, 0)
-        if ph % 2 == 0 and pw % 2 == 0:
-            return F.conv2d(x, self.weight, self.bias, self.stride, (ph // 2, pw // 2), self.dilation, self.groups)
-        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
-        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+        pad = (ph // 2, pw // 2)
+        if ph % 2 or pw % 2:
+            x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+            pad = 0
+        if _DW_NATIVE and self.groups > 1 and self.groups == self.in_channels and x.is_cuda:
+            with torch.backends.cudnn.flags(enabled=False):
+                return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
+        return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose forward may bypass MIOpen (same parameters / buffers / state-dict keys)."""
+
+    def forward(self, x):
+        if _BN_NATIVE and x.is_cuda:
+            with torch.backends.cudnn.flags(enabled=False):
+                return super().forward(x)
+        return super().forward(x)
 
 
 def _drop_connect(x, p, training):
@@ -59,14 +81,14 @@ class MBConvBlock(nn.Module):
         self.expand, self.stride, self.cin, self.cout = expand, stride, cin, cout
         if expand != 1:
             self._expand_conv = SamePadConv2d(cin, mid, 1, bias=False)
-            self._bn0 = nn.BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
+            self._bn0 = BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
         self._depthwise_conv = SamePadConv2d(mid, mid, kernel, stride=stride, groups=mid, bias=False)
-        self._bn1 = nn.BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
+        self._bn1 = BatchNorm2d(mid, momentum=_BN_MOM, eps=_BN_EPS)
         sq = max(1, int(cin * se_ratio))
         self._se_reduce = SamePadConv2d(mid, sq, 1)
         self._se_expand = SamePadConv2d(sq, mid, 1)
         self._project_conv = SamePadConv2d(mid, cout, 1, bias=False)
-        self._bn2 = nn.BatchNorm2d(cout, momentum=_BN_MOM, eps=_BN_EPS)
+        self._bn2 = BatchNorm2d(cout, momentum=_BN_MOM, eps=_BN_EPS)
 
     def forward(self, x, drop_connect_rate=None):
         inp = x
@@ -87,14 +109,14 @@ class EfficientNet(nn.Module):
         super().__init__()
         self.drop_connect_rate = drop_connect_rate
         self._conv_stem = SamePadConv2d(in_channels, 32, 3, stride=2, bias=False)
-        self._bn0 = nn.BatchNorm2d(32, momentum=_BN_MOM, eps=_BN_EPS)
+        self._bn0 = BatchNorm2d(32, momentum=_BN_MOM, eps=_BN_EPS)
         blocks = []
         for rep, k, s, e, cin, cout, se in _B0_STAGES:
             blocks.append(MBConvBlock(k, s, e, cin, cout, se))
             blocks += [MBConvBlock(k, 1, e, cout, cout, se) for _ in range(rep - 1)]
         self._blocks = nn.ModuleList(blocks)
         self._conv_head = SamePadConv2d(320, 1280, 1, bias=False)
-        self._bn1 = nn.BatchNorm2d(1280, momentum=_BN_MOM, eps=_BN_EPS)
+        self._bn1 = BatchNorm2d(1280, momentum=_BN_MOM, eps=_BN_EPS)
         self._avg_pooling = nn.AdaptiveAvgPool2d(1)
         self.classifier_ = nn.Sequential(nn.Dropout(dropout_rate), nn.Linear(1280, num_classes))
         for m in self.modules():

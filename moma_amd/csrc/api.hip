@@ -106,6 +106,14 @@ size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int p
 int moma_infonce_fused(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                        float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
                        size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream) {
+    return moma_infonce_fused_ex(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, workspace_bytes,
+                                 qdtype, prec, stream, nullptr, nullptr);
+}
+
+int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
+                          float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                          size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin,
+                          void* ev_end) {
     if (!q || !k || !queue || !loss_rows || !lse || !top1 || !workspace) return MOMA_E_NULL;
     if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
@@ -113,10 +121,13 @@ int moma_infonce_fused(const float* q, const float* k, const void* queue, int B,
     if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (infonce_flash_supported(B, d, K, qdtype, prec))
-        return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st));
+        return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,
+                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
     // staged path (any shape, exact fp32 available): logits -> row reduction -> gradient product
     float* logits = (float*)workspace;
+    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, st);
     int rc = moma_infonce_logits(q, k, queue, logits, B, d, K, inv_T, qdtype, prec, stream);
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, st);
     if (rc != MOMA_OK) return rc;
     MOMA_TRY(launch_infonce_rows(logits, B, K + 1, loss_rows, lse, top1, dq != nullptr, st));
     if (dq) return moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);

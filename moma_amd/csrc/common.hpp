@@ -76,6 +76,6 @@ bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec);
 size_t infonce_flash_workspace_bytes(int B, int d, int K);
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st);
+                                hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 
 }  // namespace moma

@@ -523,7 +523,7 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
 
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st) {
+                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     float* m_part = (float*)ws;
@@ -551,11 +551,14 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #define MOMA_FLASH_LAUNCH(DD)                                                                             \
     do {                                                                                                  \
         hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, scale_log2, qpack, p.Bpad / 32, flags + (size_t)p.nchunk * p.nbt * 4); \
+        if (ev_begin) (void)hipEventRecord(ev_begin, st);                                                 \
         if (dq) {                                                                                         \
             hipLaunchKernelGGL((infonce_flash_kernel<DD, true, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
+            if (ev_end) (void)hipEventRecord(ev_end, st);                                                 \
             hipLaunchKernelGGL((infonce_flash_kernel<DD, true, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
         } else {                                                                                          \
             hipLaunchKernelGGL((infonce_flash_kernel<DD, false, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
+            if (ev_end) (void)hipEventRecord(ev_end, st);                                                 \
             hipLaunchKernelGGL((infonce_flash_kernel<DD, false, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
         }                                                                                                 \
     } while (0)

@@ -68,6 +68,16 @@ def set_event_recorder(rec) -> None:
     _EVENT_RECORDER = rec
 
 
+# Optional (bench.py): a callable returning a (hipEvent_t, hipEvent_t) pair of raw handles that the library records
+# around the dominant kernel of the next moma_infonce_fused call (see moma_infonce_fused_ex).
+_KERNEL_EVENTS = None
+
+
+def set_kernel_event_provider(fn) -> None:
+    global _KERNEL_EVENTS
+    _KERNEL_EVENTS = fn
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -207,9 +217,11 @@ class _InfoNCEFused(torch.autograd.Function):
         qd = _qdtype(queue)
         ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        ev0, ev1 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None)
         with _timed("moma_infonce_fused"):
-            check(lib.moma_infonce_fused(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
-                                         _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream()),
+            check(lib.moma_infonce_fused_ex(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
+                                            _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream(),
+                                            C.c_void_p(ev0), C.c_void_p(ev1)),
                   "moma_infonce_fused")
         if need_grad:
             ctx.save_for_backward(dq)
