@@ -1,0 +1,138 @@
+"""Data-parallel host logic on CPU: 2 processes, gloo, 127.0.0.1.
+
+What is under test is the HOST orchestration of the N>1 path (BASELINE configs[3]): DDP on the student, the
+explicit flat all-reduce of the trainable criterion modules (fix of SURVEY Q7), per-rank queue + pointer, EMA
+teacher staying identical across ranks without communication, metric reduction, and the reference-faithful
+`gather` Shuffle-BN mode (collectives C3-C5).  There is no GPU here, and the product has no CPU path, so inside
+the spawned workers the four kernel entry points of `moma_amd.ops` are replaced by the torch-CPU restatement
+(same op order as `oracle/step_oracle.py`) -- a test-only stand-in; the product never routes through it."""
+import argparse
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _install_cpu_standins():
+    """Replace the C-ABI wrappers by torch-CPU restatements (reference op order) for host-logic tests."""
+    from moma_amd import ops
+
+    def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, prec="fp32"):
+        n, c = x.shape
+        qkv = F.linear(x, w_qkv, b_qkv).reshape(n, 3, num_heads, c // num_heads).permute(1, 2, 0, 3)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        a = ((q @ k.transpose(-2, -1)) * (c // num_heads) ** -0.5).softmax(dim=-1)
+        return F.linear((a @ v).transpose(0, 1).reshape(n, c), w_proj, b_proj)
+
+    def infonce_fused(q, k, queue, T, prec="fp32"):
+        logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().clone().t()], dim=1) / T   # pre-enqueue snapshot
+        lse = torch.logsumexp(logits, dim=1)
+        top1 = (logits[:, 0] >= logits.max(dim=1).values).to(torch.int32)
+        return lse - logits[:, 0], lse.detach(), top1
+
+    def enqueue_(queue, rows, index):
+        K = queue.shape[0]
+        ids = torch.fmod(torch.arange(rows.shape[0]) + index, K).long()
+        queue.index_copy_(0, ids, rows.to(queue.dtype))
+
+    class EmaTable:
+        def __init__(self, ps, es):
+            self.ps, self.es = list(ps), list(es)
+
+        def matches(self, ps, es):
+            return True
+
+    def ema_update_(table, m):
+        for p, e in zip(table.ps, table.es):
+            e.mul_(m).add_(p, alpha=1 - m)
+
+    ops.mha, ops.infonce_fused, ops.enqueue_, ops.EmaTable, ops.ema_update_ = mha, infonce_fused, enqueue_, EmaTable, ema_update_
+
+
+def _worker(rank, world, port, shuffle_mode, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_cpu_standins()
+    from moma_amd.backbones.resnet_cifar import resnet8
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.helper.util import reduce_tensor
+    from moma_amd.distiller_zoo import DistillKL
+
+    B, K = 4, 24
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=32, attn="self", mem="MoCo", nce_k=K, nce_t=0.15,
+                             alpha=0.9, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=None, device=torch.device("cpu"),
+                             multiprocessing_distributed=True, print_freq=10 ** 9, batch_size=B, rank=rank,
+                             local_rank=rank, node_rank=0, ngpus_per_node=world, world_size=world, s_dim=64, t_dim=64,
+                             moma_prec="fp32", moma_fused=True, shuffle_bn=shuffle_mode, trace=[])
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    ms, mt = resnet8(num_classes=10), resnet8(num_classes=10)
+    contrast = build_mem(opt)
+    kd = CMO(opt)
+    trainer = ContrastTrainer(opt)
+    trainer.local_group = dist.new_group(list(range(world)))
+    trainer.broadcast_memory(contrast)
+    trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+    optimizer = torch.optim.SGD(trainable.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    ddp = nn.parallel.DistributedDataParallel(ms)
+    mods = [ddp, mt]
+    crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
+    g = torch.Generator().manual_seed(100 + rank)          # different data shard per rank
+    loader = [(torch.randn(B, 3, 16, 16, generator=g), torch.randint(0, 10, (B,), generator=g)) for _ in range(3)]
+    torch.manual_seed(7 + (0 if shuffle_mode == "gather" else rank))
+    acc, loss = train_distill_moma(1, loader, mods, crits, trainer, contrast, optimizer, opt)
+    red = reduce_tensor(torch.tensor([acc, loss]), world).tolist()
+
+    def flat(mod):
+        return torch.cat([p.detach().reshape(-1) for p in mod.parameters()])
+
+    res = dict(index=contrast.index, student=flat(ms), teacher=flat(mt), atts_q=flat(kd.atts_q), embed_s=flat(kd.embed_s),
+               atts_k=flat(kd.atts_k), memory=contrast.memory.clone(), red=red, loss=loss,
+               atts_k_grad_none=all(p.grad is None for p in kd.atts_k.parameters()))
+    if shuffle_mode == "gather":                             # one more call to inspect the gathered keys
+        x = loader[0][0]
+        k, all_k = trainer._shuffle_bn(x, mt, kd.embed_t)
+        res.update(k_shape=tuple(k.shape), all_k_shape=tuple(all_k.shape))
+    torch.save(res, os.path.join(out, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shuffle_mode", ["per_rank", "gather"])
+def test_two_rank_data_parallel(tmp_path, shuffle_mode):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, shuffle_mode, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    B, K = 4, 24
+    # replicas stay in sync: student through DDP, criterion modules through the explicit flat all-reduce
+    assert torch.equal(r0["student"], r1["student"])
+    assert torch.allclose(r0["atts_q"], r1["atts_q"], atol=1e-7) and torch.allclose(r0["embed_s"], r1["embed_s"], atol=1e-7)
+    # EMA teacher is a function of the (identical) student only -> identical without communication
+    assert torch.allclose(r0["teacher"], r1["teacher"], atol=1e-7)
+    # atts_k never gets a gradient -> untouched and equal
+    assert r0["atts_k_grad_none"] and r1["atts_k_grad_none"] and torch.equal(r0["atts_k"], r1["atts_k"])
+    n_enq = B if shuffle_mode == "per_rank" else B * world
+    assert r0["index"] == r1["index"] == (3 * n_enq) % K
+    if shuffle_mode == "per_rank":
+        assert not torch.equal(r0["memory"], r1["memory"])           # per-rank queues hold per-rank keys
+    else:
+        assert torch.allclose(r0["memory"], r1["memory"], atol=1e-6)  # reference mode: every rank enqueues all keys
+        assert r0["all_k_shape"] == (B * world, 32) and r0["k_shape"] == (B, 32)
+    # epoch metrics are all-reduced (avg)
+    assert r0["red"] == r1["red"] and abs(r0["red"][1] - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
