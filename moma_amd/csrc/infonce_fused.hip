@@ -28,6 +28,7 @@
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
 // which is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
 #include "common.hpp"
+#include <type_traits>
 
 namespace moma {
 namespace {
@@ -43,32 +44,44 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >>
 
 // LDS-DMA of one key tile (32 keys x D bf16) into `buf`: D/16 pieces of 1 KiB (4 rows x 256 B of one segment);
 // wave w issues pieces w, w+4, ... (PPW = D/64 per wave).  `dma_piece` issues this wave's i-th piece so that the
-// issue cost (tens of cycles each) can be spread between MFMAs instead of stalling the wave at the tile top.
-// The per-lane source offsets are recomputed from an opaque copy of the lane id at every call: hoisted out of
-// the tile loop they would occupy VGPRs for the whole kernel.
+// issue cost can be spread between MFMAs instead of stalling the wave at the tile top.
+//   source offset of lane L in piece (seg, rg): row = 4*rg + (L>>4), chunk = (L&15) ^ swz(row)
+//   = [rg*4*D*2 + seg*256]  (wave-uniform, scalar)  +  lane term  (1 VGPR, computed once per kernel)
+//   Every piece of wave w has rg & 3 == w (pc = 4i + w), so a wave needs a single lane term.
+struct DmaLane {
+    unsigned term;        // (L>>4)*D*2 + ((L&15) ^ swz(4*w + (L>>4)))*16
+};
 template <int D>
-__device__ __forceinline__ void dma_piece(int i, const bf16_raw* __restrict__ queue, long key0, int K, char* buf,
-                                          int wave, int lane) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int rl = ln >> 4, slot = ln & 15;
-    const char* tile = reinterpret_cast<const char*>(queue) + key0 * (long)(D * 2);   // wave-uniform
-    const int last = (int)min((long)(KT - 1), (long)K - 1 - key0);                    // clamp rows past K (masked later)
+__device__ __forceinline__ DmaLane dma_lane_terms(int lane, int wave) {
+    DmaLane t;
+    const int rl = lane >> 4, sl = lane & 15;
+    t.term = (unsigned)(rl * (D * 2) + ((sl ^ swz(4 * wave + rl)) << 4));
+    return t;
+}
+template <int D, bool PARTIAL = true>
+__device__ __forceinline__ void dma_piece(int i, const DmaLane& dl, const bf16_raw* __restrict__ queue, long key0, int K,
+                                          char* buf, int wave, int lane) {
     const int pc = i * 4 + wave;                // wave-uniform
     const int seg = pc >> 3, rg = pc & 7;
-    const int row = rg * 4 + rl;
-    const int ch = slot ^ swz(row);
-    const unsigned off = (unsigned)min(row, last) * (unsigned)(D * 2) + seg * 256 + ch * 16;
+    const char* tile = reinterpret_cast<const char*>(queue) + key0 * (long)(D * 2) + seg * 256;   // wave-uniform
+    unsigned off = dl.term;
+    if (PARTIAL && key0 + KT > K) {             // queue's last, partial tile: clamp rows past K (masked later)
+        const int rl = lane >> 4;
+        const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
+        off = off - (unsigned)(rl * (D * 2)) + (unsigned)row * (unsigned)(D * 2);
+    } else {
+        tile += rg * 4 * (D * 2);
+    }
     char* dst = buf + seg * 8192 + rg * 1024;   // wave-uniform LDS base; lane L lands at +16*L
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + off),
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
 template <int D>
-__device__ __forceinline__ void dma_tile(const bf16_raw* __restrict__ queue, long key0, int K, char* buf, int wave,
-                                         int lane) {
+__device__ __forceinline__ void dma_tile(const DmaLane& dl, const bf16_raw* __restrict__ queue, long key0, int K,
+                                         char* buf, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < D / 64; ++i) dma_piece<D>(i, queue, key0, K, buf, wave, lane);
+    for (int i = 0; i < D / 64; ++i) dma_piece<D>(i, dl, queue, key0, K, buf, wave, lane);
 }
 
 // Q operand pre-pack: scale by log2(e)/T, round to bf16 and store in MFMA-fragment order so that every
@@ -134,6 +147,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const int ntiles = (K + KT - 1) / KT;
     const int t0 = chunk * tiles_per_chunk;
     const int t1 = min(t0 + tiles_per_chunk, ntiles);
+    const DmaLane dl = dma_lane_terms<D>(lane, wave);
     // partial slot of this wave's 32 query rows in chunk `chunk`
     const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
     int* my_flag = ovf_flag + ((long)chunk * nbt + bt) * 4;      // 4 ints per workgroup, one per wave
@@ -195,129 +209,243 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((t - t0) % NBUF) * TILE_BYTES; };
+
+    // ---- scores of one tile: X[key, q] over D.  A fragments (keys) are requested PFG groups of G k-steps ahead
+    // of the MFMAs that consume them; the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the
+    // reads behind the MFMAs and exposes the LDS latency once per group).  One LDS-DMA piece of the refill tile is
+    // issued after every MFMA group, so its issue cost hides behind the matrix pipe.
+    auto score = [&](auto refill_tag, const char* buf, f32x16& x, float init, long rkey0, char* rbuf)
+                     __attribute__((always_inline)) {
+        // One wave per SIMD issues in order: what sits between two MFMAs runs in the shadow of the first (about 24
+        // free issue cycles per 32-cycle MFMA; measured: one ds_read_b128 or one LDS-DMA piece per 4 hides fully),
+        // while long runs of non-MFMA work idle the matrix pipe.  So each k-step is "one ds_read_b128 for k-step
+        // ks+RD, [one DMA piece every 4th step], one MFMA", in exactly that order (sched_barriers).  The reads are
+        // inline asm counted by hand: hipcc's own waits were lgkmcnt(0) every 8 steps (the latency of the newest read
+        // exposed 4x per tile).  x starts at -m_ref ("row constant as the initial accumulator"): no subtraction later.
+        // refill_tag: 0 = no refill, 1 = refill with a full tile, 2 = refill with the queue's last (partial) tile.
+        constexpr int REFILL = decltype(refill_tag)::value;
+        constexpr int RD = 8;                                  // LDS read distance in k-steps (8 x 32 cycles)
+        static_assert(KS % 4 == 0 && KS / 4 == PPW, "one DMA piece per 4 k-steps");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = init;
+        const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
+        unsigned aa[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aa[c] = lbase + a_off[c];
+        f32x4 kf[RD];
+        auto rd = [&](int ks) __attribute__((always_inline)) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");
+        };
+#pragma unroll
+        for (int ks = 0; ks < RD; ++ks) rd(ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // reads ks+1 .. min(ks+RD-1, KS-1) may stay in flight
+            constexpr int dummy = 0; (void)dummy;
+            const int ahead = (KS - 1 - ks) < (RD - 1) ? (KS - 1 - ks) : (RD - 1);
+            switch (ahead) {
+                case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // inline-asm MFMA pins the score accumulator to VGPRs (through the builtin hipcc puts it in a[0:15] and
+            // moves O's first column tile out and back every tile).  Hazards by hand: s_nop before the first MFMA
+            // (VALU-written C), s_nops after the last one (VALU readers of D).
+            if (ks == 0)
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+            else if (ks == KS - 1)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+            if (ks + RD < KS) rd(ks + RD);
+            if constexpr (REFILL != 0) {
+                if ((ks & 3) == 1) dma_piece<D, REFILL == 2>(ks >> 2, dl, queue, rkey0, K, rbuf, wave, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // run `score` with the refill mode chosen once per tile (one branch instead of three per DMA piece)
+    auto score_dispatch = [&](const char* buf, f32x16& x, float init, bool refill, int rtile) __attribute__((always_inline)) {
+        const long rkey0 = (long)rtile * KT;
+        char* rbuf = slot(rtile);
+        if (!refill) score(std::integral_constant<int, 0>{}, buf, x, init, rkey0, rbuf);
+        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, buf, x, init, rkey0, rbuf);
+        else score(std::integral_constant<int, 1>{}, buf, x, init, rkey0, rbuf);
+    };
+    // keys past K (only in the queue's last tile) get -inf scores; key of register r = (r&3) + 8*(r>>2) + 4*h
+    auto mask_tail = [&](f32x16& x, int t) __attribute__((always_inline)) {
+        if ((t + 1) * KT > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
+        }
+    };
+    // tile statistics after its 16 scores were visited: true max (top-1), overflow check against the reference
+    auto tile_stats = [&](float tmax) __attribute__((always_inline)) {
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        mx = fmaxf(mx, tmax);
+        if constexpr (!REPAIR) ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
+    };
+    auto pack = [&](const f32x16& p, bf16x8 (&pa)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            pa[s] = bf16x8{(__bf16)p[8 * s + 0], (__bf16)p[8 * s + 1], (__bf16)p[8 * s + 2], (__bf16)p[8 * s + 3],
+                           (__bf16)p[8 * s + 4], (__bf16)p[8 * s + 5], (__bf16)p[8 * s + 6], (__bf16)p[8 * s + 7]};
+    };
+    // softmax numerators of one tile, all at once (prologue tile / un-pipelined paths): x <- 2^(x - m_ref)
+    auto softmax_plain = [&](f32x16& x, int t, bool first) __attribute__((always_inline)) {
+        mask_tail(x, t);
+        float tmax = x[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
+        if constexpr (!REPAIR) {
+            if (first) m_ref = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+        tile_stats(tmax);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);
+            psum += x[r];
+        }
+        l_run += psum;
+    };
+    // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols].  The transposed reads are inline asm: through the builtin
+    // hipcc orders every ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain
+    // the tile ring.  They are counted by hand: fragments of column tile c+PF are requested before tile c's MFMAs,
+    // so "tile c has arrived" is lgkmcnt(4*PF) (LDS returns in order).  `between(c)` is executed in the shadow of
+    // column tile c's two MFMAs (the pipelined loop puts one step of the NEXT tile's softmax there).
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto pv = [&](const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
+        if constexpr (WITH_DQ) {
+            constexpr int PF = 2;
+            const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
+            unsigned ba[4][2];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                ba[c4][0] = lbase + b_off[c4][0];
+                ba[c4][1] = lbase + b_off[c4][1];
+            }
+            s16x4 kb[PF + 1][4];
+            auto issue = [&](int c) __attribute__((always_inline)) {
+                s16x4* k4 = kb[c % (PF + 1)];
+                const int imm = (c >> 2) * 8192;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
+            };
+#pragma unroll
+            for (int c = 0; c < PF; ++c) issue(c);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                if (c + PF < NCT) issue(c + PF);
+                const int ahead = (c + PF < NCT) ? PF : (NCT - 1 - c);
+                if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                s16x4* k4 = kb[c % (PF + 1)];
+                const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
+                between(c);
+                __builtin_amdgcn_sched_barrier(0);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
 #pragma unroll
     for (int j = 0; j < NBUF - 1; ++j)
-        if (t0 + j < t1) dma_tile<D>(queue, (long)(t0 + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+        if (t0 + j < t1) dma_tile<D>(dl, queue, (long)(t0 + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
     wait_tiles_in_flight(min(t1 - t0, NBUF - 1) - 1);
     __builtin_amdgcn_s_barrier();
 
-#pragma unroll 1
-    for (int t = t0; t < t1; ++t) {
-        char* buf = smem + ((t - t0) % NBUF) * TILE_BYTES;
-        // the ring slot every wave finished reading before the barrier that ended tile t-1 is refilled with tile
-        // t+NBUF-1; its PPW pieces are issued between the MFMA groups of the score product below
-        const bool refill = t + NBUF - 1 < t1;
-        char* rbuf = smem + ((t - t0 + NBUF - 1) % NBUF) * TILE_BYTES;
-        const long rkey0 = (long)(t + NBUF - 1) * KT;
-        if (!active && refill) dma_tile<D>(queue, rkey0, K, rbuf, wave, lane);
-        if (active) {
-            // ---- scores: X[key, q] over D ; fragments fetched one group (4 k-steps) ahead of their MFMAs
-            f32x16 x;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = 0.f;
-            {
-                // A fragments (keys) are requested PFG groups of G k-steps ahead of the MFMAs that consume them;
-                // the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the reads behind the
-                // MFMAs and exposes the LDS latency once per group)
-                constexpr int G = 4, NG = KS / G, PFG = 2;
-                bf16x8 kf[PFG + 1][G];
-                auto rd = [&](int g) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int i = 0; i < G; ++i) {
-                        const int ks = g * G + i;
-                        kf[g % (PFG + 1)][i] = *reinterpret_cast<const bf16x8*>(buf + (ks >> 3) * 8192 + a_off[ks & 7]);
-                    }
-                };
-#pragma unroll
-                for (int g = 0; g < PFG; ++g)
-                    if (g < NG) rd(g);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + PFG < NG) rd(g + PFG);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < G; ++i)
-                        x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g % (PFG + 1)][i], qf[g * G + i], x, 0, 0, 0);
-                    static_assert(NG == PPW, "one DMA piece per MFMA group");
-                    if (refill) dma_piece<D>(g, queue, rkey0, K, rbuf, wave, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // key of register r on this lane: (r&3) + 8*(r>>2) + 4*h
-            if ((t + 1) * KT > K) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KT + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= K) x[r] = NEG_BIG;
-                }
-            }
-            float tmax = x[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            mx = fmaxf(mx, tmax);
-            if constexpr (!REPAIR) {
-                if (t == t0) m_ref = tmax;
-                ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
-            }
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);
-                psum += x[r];
-            }
-            l_run += psum;
-            if constexpr (WITH_DQ) {
-                bf16x8 pa[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    pa[s] = bf16x8{(__bf16)x[8 * s + 0], (__bf16)x[8 * s + 1], (__bf16)x[8 * s + 2], (__bf16)x[8 * s + 3],
-                                   (__bf16)x[8 * s + 4], (__bf16)x[8 * s + 5], (__bf16)x[8 * s + 6], (__bf16)x[8 * s + 7]};
-                // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols]
-                // The transposed reads are issued as inline asm: through the builtin hipcc orders every
-                // ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the
-                // tile ring.  The asm reads are counted by hand: fragments of column tile c+PF are requested
-                // before tile c's MFMAs, so "tile c has arrived" is lgkmcnt(4*PF) (LDS returns in order).
-                constexpr int PF = 2;
-                const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
-                unsigned ba[4][2];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    ba[c4][0] = lbase + b_off[c4][0];
-                    ba[c4][1] = lbase + b_off[c4][1];
-                }
-                s16x4 kb[PF + 1][4];
-                auto issue = [&](int c) __attribute__((always_inline)) {
-                    s16x4* k4 = kb[c % (PF + 1)];
-                    const int imm = (c >> 2) * 8192;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
-                };
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-#pragma unroll
-                for (int c = 0; c < PF; ++c) issue(c);
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) {
-                    if (c + PF < NCT) issue(c + PF);
-                    const int ahead = (c + PF < NCT) ? PF : (NCT - 1 - c);
-                    if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                    else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    s16x4* k4 = kb[c % (PF + 1)];
-                    const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
-                    O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
-                    O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // tile t+1 must have landed (tiles t+2.. may stay in flight); every wave must be done with this buffer
-        wait_tiles_in_flight(min(t + NBUF - 1, t1 - 1) - (t + 1));
+    if constexpr (WITH_DQ && !REPAIR) {
+        // ---- software-pipelined main loop (one wave per SIMD: nothing else hides the softmax's VALU time):
+        //   iteration t:  X(t+1) = scores of tile t+1            [matrix pipe; DMA pieces of tile t+3 in its shadow]
+        //                 O += P(t).K(t)  ||  P(t+1) = softmax numerators of X(t+1), one register per column tile
+        // Live ring slots: t, t+1 ; in flight: t+2, t+3.
+        f32x16 xa;
+        bf16x8 pa[2];
+        score_dispatch(slot(t0), xa, 0.f, t0 + NBUF - 1 < t1, t0 + NBUF - 1);
+        softmax_plain(xa, t0, true);
+        pack(xa, pa);
+        // tile t0+1 must have landed before the loop's first score
+        wait_tiles_in_flight(min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) > 0 ? min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) : 0);
         __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = t0; t < t1; ++t) {
+            const bool has_next = t + 1 < t1;
+            f32x16 xb;
+            if (has_next) {
+                // slot of tile t-1 (free since the barrier that ended iteration t-1) takes tile t+NBUF-1... which is
+                // tile (t+1)+NBUF-2; with NBUF = 4 the refill target during iteration t is tile t+3 -> slot of t-1
+                const bool refill = t >= t0 + 1 && t + NBUF - 1 < t1;
+                score_dispatch(slot(t + 1), xb, -m_ref, refill, t + NBUF - 1);
+                mask_tail(xb, t + 1);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xb[r] = NEG_BIG;
+            }
+            float tmax = NEG_BIG, psum = 0.f;
+            pv(slot(t), pa, [&](int c) __attribute__((always_inline)) {
+                if (c < 16) {                                   // xb already holds score - m_ref
+                    tmax = fmaxf(tmax, xb[c]);
+                    xb[c] = __builtin_amdgcn_exp2f(xb[c]);
+                    psum += xb[c];
+                }
+            });
+            if constexpr (NCT < 16) {
+#pragma unroll
+                for (int c = NCT; c < 16; ++c) {
+                    tmax = fmaxf(tmax, xb[c]);
+                    xb[c] = __builtin_amdgcn_exp2f(xb[c]);
+                    psum += xb[c];
+                }
+            }
+            if (has_next) {
+                tile_stats(tmax + m_ref);                       // back to absolute log2 units
+                l_run += psum;
+                pack(xb, pa);
+            }
+            // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
+            {
+                const int newest = min(t + NBUF - 1, t1 - 1);
+                wait_tiles_in_flight(newest - (t + 2) > 0 ? newest - (t + 2) : 0);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ---- plain loop (forward-only and repair variants): score, softmax, (P.K), one tile at a time
+#pragma unroll 1
+        for (int t = t0; t < t1; ++t) {
+            const bool refill = t + NBUF - 1 < t1;
+            if (!active && refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
+            if (active) {
+                f32x16 x;
+                score_dispatch(slot(t), x, 0.f, refill, t + NBUF - 1);
+                softmax_plain(x, t, t == t0);
+                if constexpr (WITH_DQ) {
+                    bf16x8 pa[2];
+                    pack(x, pa);
+                    pv(slot(t), pa, [&](int) __attribute__((always_inline)) {});
+                }
+            }
+            // tile t+1 must have landed (tiles t+2.. may stay in flight); every wave must be done with this slot
+            wait_tiles_in_flight(min(t + NBUF - 1, t1 - 1) - (t + 1));
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
@@ -336,21 +464,16 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             }
         }
         if constexpr (WITH_DQ) {
-            // O partial as bf16 pairs [row][D/2]: neighbouring lanes hold neighbouring columns, so even lanes take
-            // both columns of row(r) and odd lanes both columns of row(r+1) -> one 4-byte store per lane
-            const int odd = n & 1;
+            // O partial in REGISTER order, no cross-lane traffic: registers 2j and 2j+1 of a lane are two adjacent
+            // query rows of one column -> one packed bf16 pair per lane, 256 B per wave-instruction:
+            //   o_part[wave block][(c*8 + j)*64 + lane] = { O[row(2j,h)][32c+n] , O[row(2j+1,h)][32c+n] }
+            // (row(r,h) = (r&3) + 8*(r>>2) + 4*h ; the combine kernel undoes the mapping per row pair)
+            unsigned* dst = o_part + ((long)chunk * (Bpad / 32) + bt * 4 + wave) * (long)(NCT * 8 * 64) + lane;
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float e = O[c][r], o = O[c][r + 1];
-                    const float recv = __shfl_xor(odd ? e : o, 1, 64);
-                    const float lo = odd ? recv : e, hi = odd ? o : recv;
-                    const int rr = r + odd;
-                    const int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-                    const unsigned pk = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-                    o_part[(prow + row) * (D / 2) + c * 16 + (n >> 1)] = pk;
-                }
+                for (int j = 0; j < 8; ++j)
+                    dst[(c * 8 + j) * 64] = (unsigned)f32_to_bf16(O[c][2 * j]) | ((unsigned)f32_to_bf16(O[c][2 * j + 1]) << 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -379,7 +502,9 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const uint4* __re
     }
 }
 
-// merge the key chunks of one query row, add the positive logit (exact fp32), emit loss / lse / top-1 / dq
+// merge the key chunks of a PAIR of adjacent query rows (2m, 2m+1 -- they share the packed O words), add the
+// positive logit (exact fp32), emit loss / lse / top-1 / dq.  128 threads per row for the scalars; for dq the 256
+// threads are 4 chunk-groups x 64 lanes, a lane owning 4 adjacent packed words (16-B loads = 4 columns x 2 rows).
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                int B, int D, float inv_T, int nchunk, int Bpad,
                                                                const unsigned* __restrict__ o_part,
@@ -388,100 +513,99 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                const float* __restrict__ x_part,
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq) {
-    __shared__ float red[4];
-    __shared__ float wts[1024];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ float red[2][2];
+    __shared__ float wts[2][1024];
+    __shared__ float accs[4][2][520];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int rsel = tid >> 7;                       // which row of the pair this half of the block reduces
+    const int t128 = tid & 127;
+    const int b = blockIdx.x * 2 + rsel;
+    const bool live = b < B;
+    const int bb = live ? b : B - 1;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    auto pair_sum = [&](float v) { v = wave_sum(v); __syncthreads(); if (lane == 0) red[rsel][wid & 1] = v; __syncthreads(); return red[rsel][0] + red[rsel][1]; };
+    auto pair_max = [&](float v) { v = wave_max(v); __syncthreads(); if (lane == 0) red[rsel][wid & 1] = v; __syncthreads(); return fmaxf(red[rsel][0], red[rsel][1]); };
     // positive logit
     float s = 0.f;
-    for (int c = tid; c < D; c += 256) s = fmaf(q[(long)b * D + c], k[(long)b * D + c], s);
-    s = wave_sum(s);
-    if (lane == 0) red[wid] = s;
-    __syncthreads();
-    const float s0 = (red[0] + red[1] + red[2] + red[3]) * inv_T;
+    for (int c = t128; c < D; c += 128) s = fmaf(q[(long)bb * D + c], k[(long)bb * D + c], s);
+    const float s0 = pair_sum(s) * inv_T;
     const float s0l = s0 * LOG2E;
-    __syncthreads();
     float M = NEG_BIG, X = NEG_BIG;
-    for (int c = tid; c < nchunk; c += 256) {
-        M = fmaxf(M, m_part[(long)c * Bpad + b]);
-        X = fmaxf(X, x_part[(long)c * Bpad + b]);
+    for (int c = t128; c < nchunk; c += 128) {
+        M = fmaxf(M, m_part[(long)c * Bpad + bb]);
+        X = fmaxf(X, x_part[(long)c * Bpad + bb]);
     }
-    M = wave_max(M);
-    X = wave_max(X);
-    if (lane == 0) red[wid] = M;
-    __syncthreads();
-    M = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), s0l);
-    __syncthreads();
-    if (lane == 0) red[wid] = X;
-    __syncthreads();
-    X = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
+    M = fmaxf(pair_max(M), s0l);
+    X = pair_max(X);
     float L = 0.f;
-    for (int c = tid; c < nchunk; c += 256) {
-        const float w = exp2f(m_part[(long)c * Bpad + b] - M);
-        wts[c] = w;
-        L += w * l_part[(long)c * Bpad + b];
+    for (int c = t128; c < nchunk; c += 128) {
+        const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
+        wts[rsel][c] = w;
+        L += w * l_part[(long)c * Bpad + bb];
     }
-    L = wave_sum(L);
-    if (lane == 0) red[wid] = L;
-    __syncthreads();
     const float p0u = exp2f(s0l - M);
-    L = red[0] + red[1] + red[2] + red[3] + p0u;
+    L = pair_sum(L) + p0u;
     const float lse = (M + log2f(L)) * LN2;
-    if (tid == 0) {
+    if (t128 == 0 && live) {
         lse_out[b] = lse;
         loss_rows[b] = lse - s0;
         top1[b] = (s0l >= X) ? 1 : 0;
     }
     if (dq != nullptr) {
-        // 4 groups of 64 threads take the chunks j = g, g+4, ...; a thread owns 8 adjacent columns (one 16-B load
-        // of bf16 per chunk, 8 loads in flight); the 4 group sums meet in LDS
-        __shared__ float accs[4][520];
-        const float invL = 1.f / L;
-        const float cpos = p0u * invL - 1.f;
+        // rows 2m, 2m+1 -> wave block, register pair j, lane half h  (q = row & 31 = (r&3) + 8*(r>>2) + 4*h)
+        const int row0 = blockIdx.x * 2;
+        const int qq = row0 & 31, h = (qq >> 2) & 1, r0 = (qq & 3) + 4 * (qq >> 3), j = r0 >> 1;
+        const int nct = D / 32;
+        const long wb_stride = (long)nct * 8 * 64;                      // words per wave block
+        const long chunk_stride = (long)(Bpad / 32) * wb_stride;
+        const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + j * 64 + 32 * h;
         const int g = tid >> 6, tg = tid & 63;
-        const int n8 = D / 8;
-        __syncthreads();                                   // wts[] complete
-        for (int c8 = tg; c8 < n8; c8 += 64) {
-            float a[8];
+        __syncthreads();                                                 // wts[][] complete
+        for (int c4 = tg; c4 < D / 4; c4 += 64) {                       // 4 adjacent columns: same column tile
+            const int col = c4 * 4, c = col >> 5, n = col & 31;
+            const uint4* src = reinterpret_cast<const uint4*>(base + (long)c * 8 * 64 + n);
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            int jc = g;
+            for (; jc + 12 < nchunk; jc += 16) {
+                uint4 v[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = 0.f;
-            const uint4* src = reinterpret_cast<const uint4*>(o_part + (long)b * (D / 2)) + c8;
-            const long stride = (long)Bpad * (D / 8);      // uint4 per chunk
-            int j = g;
-            for (; j + 28 < nchunk; j += 32) {
-                uint4 v[8];
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(src) + (long)(jc + 4 * u) * chunk_stride);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(long)(j + 4 * u) * stride];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float w = wts[j + 4 * u];
+                for (int u = 0; u < 4; ++u) {
+                    const float w0 = wts[0][jc + 4 * u], w1 = wts[1][jc + 4 * u];
                     const unsigned vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        a[2 * i] = fmaf(w, __uint_as_float(vv[i] << 16), a[2 * i]);
-                        a[2 * i + 1] = fmaf(w, __uint_as_float(vv[i] & 0xffff0000u), a[2 * i + 1]);
+                        a0[i] = fmaf(w0, __uint_as_float(vv[i] << 16), a0[i]);
+                        a1[i] = fmaf(w1, __uint_as_float(vv[i] & 0xffff0000u), a1[i]);
                     }
                 }
             }
-            for (; j < nchunk; j += 4) {
-                const uint4 v = src[(long)j * stride];
-                const float w = wts[j];
+            for (; jc < nchunk; jc += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(src) + (long)jc * chunk_stride);
+                const float w0 = wts[0][jc], w1 = wts[1][jc];
                 const unsigned vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    a[2 * i] = fmaf(w, __uint_as_float(vv[i] << 16), a[2 * i]);
-                    a[2 * i + 1] = fmaf(w, __uint_as_float(vv[i] & 0xffff0000u), a[2 * i + 1]);
+                    a0[i] = fmaf(w0, __uint_as_float(vv[i] << 16), a0[i]);
+                    a1[i] = fmaf(w1, __uint_as_float(vv[i] & 0xffff0000u), a1[i]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) accs[g][c8 * 8 + i] = a[i];
+            for (int i = 0; i < 4; ++i) {
+                accs[g][0][col + i] = a0[i];
+                accs[g][1][col + i] = a1[i];
+            }
         }
         __syncthreads();
-        for (int c = tid; c < D; c += 256) {
-            const float acc = accs[0][c] + accs[1][c] + accs[2][c] + accs[3][c];
-            const long o = (long)b * D + c;
-            dq[o] = (cpos * k[o] + acc * invL) * inv_T;
+        if (live) {
+            const float invL = 1.f / L;
+            const float cpos = p0u * invL - 1.f;
+            for (int c = t128; c < D; c += 128) {
+                const float acc = accs[0][rsel][c] + accs[1][rsel][c] + accs[2][rsel][c] + accs[3][rsel][c];
+                const long o = (long)b * D + c;
+                dq[o] = (cpos * k[o] + acc * invL) * inv_T;
+            }
         }
     }
 }
@@ -569,7 +693,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(infonce_combine_kernel, dim3(B), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
+    hipLaunchKernelGGL(infonce_combine_kernel, dim3((B + 1) / 2), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
                        m_part, l_part, x_part, loss_rows, lse, top1, dq);
     return hipGetLastError();
 }
