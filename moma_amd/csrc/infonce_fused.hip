@@ -335,31 +335,39 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 ba[c4][1] = lbase + b_off[c4][1];
             }
             s16x4 kb[PF + 1][4];
-            auto issue = [&](int c) __attribute__((always_inline)) {
+            auto issue_lo = [&](int c) __attribute__((always_inline)) {
                 s16x4* k4 = kb[c % (PF + 1)];
                 const int imm = (c >> 2) * 8192;
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
+            };
+            auto issue_hi = [&](int c) __attribute__((always_inline)) {
+                s16x4* k4 = kb[c % (PF + 1)];
+                const int imm = (c >> 2) * 8192;
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
             };
 #pragma unroll
-            for (int c = 0; c < PF; ++c) issue(c);
+            for (int c = 0; c < PF; ++c) {
+                issue_lo(c);
+                issue_hi(c);
+            }
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-                if (c + PF < NCT) issue(c + PF);
-                const int ahead = (c + PF < NCT) ? PF : (NCT - 1 - c);
-                if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                // in flight when tile c's first MFMA issues: all of c+1 .. c+PF-1, nothing of c+PF yet
+                const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
+                if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 s16x4* k4 = kb[c % (PF + 1)];
                 const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
                 const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
-                between(c);
+                if (c + PF < NCT) issue_lo(c + PF);               // LDS requests in the first MFMA's shadow
                 __builtin_amdgcn_sched_barrier(0);
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
+                if (c + PF < NCT) issue_hi(c + PF);
+                between(c);                                        // one softmax step in the second MFMA's shadow
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
