@@ -57,6 +57,7 @@ class MoCo(BaseMoCo):
         self.memory = F.normalize(self.memory)
         if queue_dtype != torch.float32:
             self.memory = self.memory.to(queue_dtype)
+        self._shadow, self._shadow_key = None, None
 
     def forward(self, q, k, all_k=None):
         """Reference-compatible: materialised logits and zero labels, then enqueue (:77-100)."""
@@ -71,15 +72,32 @@ class MoCo(BaseMoCo):
         self._update_pointer(all_k.size(0))
         return logits, labels
 
+    def _bf16_shadow(self):
+        """bf16 mirror of an fp32 `memory` for the bf16 policy: the one-pass kernel streams 2-byte rows (half the
+        bytes, LDS-DMA without conversion) while `memory` keeps the reference's fp32 storage / state_dict.  The
+        bf16 MFMA path rounds the keys to bf16 anyway, so results are identical to reading the fp32 rows.  Rebuilt
+        when `memory` was replaced (.cuda(), load_state_dict) or modified in place by anything but _update_memory."""
+        mem = self.memory
+        key = (mem.data_ptr(), mem._version, tuple(mem.shape))
+        if self._shadow is None or self._shadow_key != key or self._shadow.device != mem.device:
+            self._shadow = mem.to(torch.bfloat16)
+            self._shadow_key = key
+        return self._shadow
+
     def forward_fused(self, q, k, all_k=None):
         """One pass over the queue -> (loss_kd, top-1 accuracy in percent [1]); then enqueue.
 
         loss_kd == CrossEntropyLoss(logits, zeros) of the reference loop; its gradient w.r.t. q is produced
         by the same kernel from the pre-enqueue queue, so no clone is needed."""
         k = k.detach()
-        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory, self.T, self.precision)
+        shadow = None
+        if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
+            shadow = self._bf16_shadow()
+        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision)
         all_k = all_k if all_k is not None else k
         self._update_memory(all_k, self.memory)
+        if shadow is not None:
+            self._update_memory(all_k, shadow)            # same rows, rounded to bf16 (keeps the mirror exact)
         self._update_pointer(all_k.size(0))
         return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
 

@@ -1,0 +1,29 @@
+"""End-to-end CLI on the GPU: `train_student_moma.py --distill moma` with the reference's flags on synthetic data
+(1 process, 1 GPU), fused and reference-sequence KD paths; checks it trains, checkpoints and logs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--no_fused", "--moma_prec", "fp32", "--queue_dtype", "bf16"]])
+def test_cli_trains_on_synthetic(tmp_path, extra):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "train_student_moma.py"), "--distill", "moma", "--model_s", "resnet8x4",
+           "--model_t", "resnet8x4", "--dataset", "cifar100", "--n_cls", "2", "--batch_size", "32", "--epochs", "2",
+           "--steps_per_epoch", "6", "--nce_k", "1024", "--head", "mlp", "--feat_dim", "128", "-c", "1", "-d", "1", "-b", "1",
+           "--print_freq", "3", "--save_root", str(tmp_path)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "images/sec" in r.stdout and "best accuracy" in r.stdout
+    saved = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs]
+    assert any(f.endswith("net_best_acc.pth") for f in saved)
+    params = [f for f in saved if f.endswith("parameters.json")]
+    assert params and json.load(open(params[0]))["nce_t"] == 0.15       # forced for --distill moma (reference :135)

@@ -277,3 +277,34 @@ def test_abi_argument_checks(ops):
     assert b"workspace" in lib.moma_error_string(-5)
     with pytest.raises(_lib.MomaHipError):
         ops.enqueue_(torch.zeros(4, 8), torch.zeros(2, 8), 0)      # CPU tensors are refused, no fallback
+
+
+# ------------------------------------------------------------------------------------------------ MoCo module
+def test_moco_fp32_storage_uses_bf16_mirror(ops):
+    """fp32 `memory` (reference storage) + bf16 policy: forward_fused streams a bf16 mirror kept in sync by the
+    enqueue; results equal a bf16-stored queue bit for bit, `memory` itself stays the exact fp32 ring buffer."""
+    from moma_amd.MoMA.mem_moco import MoCo
+    torch.manual_seed(3)
+    d, K, B = 256, 4096, 64
+    m32 = MoCo(d, K, 0.15, precision="bf16").cuda()
+    m16 = MoCo(d, K, 0.15, queue_dtype=torch.bfloat16, precision="bf16").cuda()
+    m16.memory.copy_(m32.memory.to(torch.bfloat16))
+    ref_mem = m32.memory.cpu().numpy().copy()
+    idx = 0
+    for step in range(3):
+        q = torch.nn.functional.normalize(torch.randn(B, d, device="cuda")).requires_grad_(True)
+        q2 = q.detach().clone().requires_grad_(True)
+        k = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
+        l32, a32 = m32.forward_fused(q, k)
+        l16, a16 = m16.forward_fused(q2, k)
+        l32.backward(); l16.backward()
+        assert l32.item() == l16.item() and torch.equal(q.grad, q2.grad)
+        O.update_memory(ref_mem, k.cpu().numpy(), idx)
+        idx = (idx + B) % K
+        assert m32.index == idx and np.array_equal(m32.memory.cpu().numpy(), ref_mem)
+        assert torch.equal(m32._shadow, m32.memory.to(torch.bfloat16))
+    # an external in-place edit of `memory` invalidates the mirror
+    m32.memory.mul_(0.5)
+    q = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
+    m32.forward_fused(q, q)
+    assert torch.equal(m32._shadow[B:], m32.memory.to(torch.bfloat16)[B:])
