@@ -16,35 +16,78 @@ template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
 
-// Stage a [64 rows] x [BK k] tile of X into S[row][k] (fp32), zero-filling out-of-range elements.
-//   X(row,k) = trans ? X[k*ld + row] : X[row*ld + k]
-template <typename T>
-__device__ __forceinline__ void stage_tile(float (*S)[LDK], const T* __restrict__ X, long ld, int trans, int r0,
-                                           int rows, int k0, int kend, int tid) {
-    if (!trans) {
+// One 64 x BK operand tile travels global -> registers -> LDS.  The two halves are split so that the global loads
+// of tile k+1 are in flight while tile k is multiplied (the problems here are M = 256-class: latency-bound, few
+// workgroups, so nothing else hides the ~2 us of a dependent HBM/L2 round trip per k-step).
+//   X(row,k) = trans ? X[k*ld + row] : X[row*ld + k]; out-of-range elements read as zero.
+// VEC: 16-byte loads along the contiguous dimension (needs fp32 data, ld % 4 == 0, 16-B aligned base).
+struct TileRegs {
+    float v[8];
+};
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, long ld, int trans, int r0, int rows,
+                                          int k0, int kend, int tid) {
+    if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < (64 * BK) / 256; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 256;
-            const int r = idx >> 5, c = idx & 31;
-            const int gr = r0 + r, gk = k0 + c;
-            float v = 0.f;
-            if (gr < rows && gk < kend) v = ldf<T>(X + (long)gr * ld + gk);
-            S[r][c] = v;
+            int gr, gk;
+            if (!trans) { gr = r0 + (idx >> 3); gk = k0 + (idx & 7) * 4; }          // 4 consecutive k of one row
+            else { gk = k0 + (idx >> 4); gr = r0 + (idx & 15) * 4; }                // 4 consecutive rows of one k
+            const long off = trans ? (long)gk * ld + gr : (long)gr * ld + gk;
+            const int lim = trans ? rows - gr : kend - gk;                          // valid elements along the vector
+            const bool other_ok = trans ? (gk < kend) : (gr < rows);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (other_ok && lim >= 4) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(X) + off);
+            else if (other_ok && lim > 0) {
+                const float* p = reinterpret_cast<const float*>(X) + off;
+                v.x = p[0];
+                if (lim > 1) v.y = p[1];
+                if (lim > 2) v.z = p[2];
+            }
+            t.v[4 * i + 0] = v.x; t.v[4 * i + 1] = v.y; t.v[4 * i + 2] = v.z; t.v[4 * i + 3] = v.w;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < (64 * BK) / 256; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
-            const int kr = idx >> 6, c = idx & 63;
-            const int gr = r0 + c, gk = k0 + kr;
+            int gr, gk;
+            if (!trans) { gr = r0 + (idx >> 5); gk = k0 + (idx & 31); }
+            else { gk = k0 + (idx >> 6); gr = r0 + (idx & 63); }
             float v = 0.f;
-            if (gr < rows && gk < kend) v = ldf<T>(X + (long)gk * ld + gr);
-            S[c][kr] = v;
+            if (gr < rows && gk < kend) v = ldf<T>(X + (trans ? (long)gk * ld + gr : (long)gr * ld + gk));
+            t.v[i] = v;
         }
     }
 }
 
-template <int PREC, typename TB>
+template <bool VEC>
+__device__ __forceinline__ void store_tile(float (*S)[LDK], const TileRegs& t, int trans, int tid) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            if (!trans) {
+                *reinterpret_cast<float4*>(&S[idx >> 3][(idx & 7) * 4]) =
+                    make_float4(t.v[4 * i], t.v[4 * i + 1], t.v[4 * i + 2], t.v[4 * i + 3]);
+            } else {
+                const int kr = idx >> 4, c = (idx & 15) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S[c + j][kr] = t.v[4 * i + j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            if (!trans) S[idx >> 5][idx & 31] = t.v[i];
+            else S[idx & 63][idx >> 6] = t.v[i];
+        }
+    }
+}
+
+template <int PREC, typename TB, bool VECA, bool VECB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BM][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN][LDK];
@@ -68,10 +111,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
+    TileRegs ra, rb;
+    if (kbeg < kend) {
+        load_tile<float, VECA>(ra, A, g.lda, g.transA, m0, g.M, kbeg, kend, tid);
+        load_tile<TB, VECB>(rb, B, g.ldb, g.transB, n0, g.N, kbeg, kend, tid);
+    }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage_tile<float>(As, A, g.lda, g.transA, m0, g.M, k0, kend, tid);
-        stage_tile<TB>(Bs, B, g.ldb, g.transB, n0, g.N, k0, kend, tid);
+        store_tile<VECA>(As, ra, g.transA, tid);
+        store_tile<VECB>(Bs, rb, g.transB, tid);
         __syncthreads();
+        if (k0 + BK < kend) {                      // next tile's loads fly while this one is multiplied
+            load_tile<float, VECA>(ra, A, g.lda, g.transA, m0, g.M, k0 + BK, kend, tid);
+            load_tile<TB, VECB>(rb, B, g.ldb, g.transB, n0, g.N, k0 + BK, kend, tid);
+        }
         if constexpr (PREC == MOMA_PREC_BF16) {
             bf16x8 af[2], bf[2];
 #pragma unroll
@@ -130,16 +182,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.splitk);
+namespace {
+template <int PREC, typename TB>
+void launch_variant(const GemmArgs& a, dim3 grid, bool va, bool vb, hipStream_t s) {
     dim3 block(256);
+    if (va && vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, true>), grid, block, 0, s, a);
+    else if (va) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, false>), grid, block, 0, s, a);
+    else if (vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, false>), grid, block, 0, s, a);
+}
+inline bool vec_ok(const void* p, long ld, long stride, int batch) {
+    return ((uintptr_t)p % 16) == 0 && ld % 4 == 0 && (batch == 1 || stride % 4 == 0);
+}
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0 || a_in.N <= 0 || a_in.batch <= 0) return hipSuccess;
+    GemmArgs a = a_in;
+    const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
+    // Few output tiles (M = 256-class problems): split K over workgroups and combine with fp32 atomics into a
+    // zeroed C, so the launch covers the chip.  Only when the caller did not choose a split itself.
+    if (a.splitk == 1 && !a.atomic && tiles < 128 && a.K >= 4 * BK && a.ldc == a.N && a.batch == 1) {
+        int sk = (256 + tiles - 1) / tiles;
+        const int ktiles = (a.K + BK - 1) / BK;
+        if (sk > ktiles / 2) sk = ktiles / 2;
+        if (sk > 16) sk = 16;
+        if (sk > 1) {
+            hipError_t e = hipMemsetAsync(a.C, 0, (size_t)a.M * a.N * sizeof(float), s);
+            if (e != hipSuccess) return e;
+            a.splitk = sk;
+            a.atomic = 1;
+        }
+    }
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.splitk);
+    const bool va = vec_ok(a.A, a.lda, a.strideA, a.batch);
+    const bool vb = a.b_dtype == MOMA_DT_F32 && vec_ok(a.B, a.ldb, a.strideB, a.batch);
     if (a.prec == MOMA_PREC_BF16) {
-        if (a.b_dtype == MOMA_DT_BF16) hipLaunchKernelGGL((gemm_kernel<MOMA_PREC_BF16, bf16_raw>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<MOMA_PREC_BF16, float>), grid, block, 0, s, a);
+        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_BF16, bf16_raw>(a, grid, va, false, s);
+        else launch_variant<MOMA_PREC_BF16, float>(a, grid, va, vb, s);
     } else {
-        if (a.b_dtype == MOMA_DT_BF16) hipLaunchKernelGGL((gemm_kernel<MOMA_PREC_F32, bf16_raw>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<MOMA_PREC_F32, float>), grid, block, 0, s, a);
+        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_F32, bf16_raw>(a, grid, va, false, s);
+        else launch_variant<MOMA_PREC_F32, float>(a, grid, va, vb, s);
     }
     return hipGetLastError();
 }
