@@ -209,7 +209,8 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((t - t0) % NBUF) * TILE_BYTES; };
+    static_assert((NBUF & (NBUF - 1)) == 0, "ring size must be a power of two");
+    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((unsigned)(t - t0) & (NBUF - 1)) * TILE_BYTES; };
 
     // ---- scores of one tile: X[key, q] over D.  A fragments (keys) are requested PFG groups of G k-steps ahead
     // of the MFMAs that consume them; the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the
@@ -326,7 +327,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     auto pv = [&](const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
         if constexpr (WITH_DQ) {
-            constexpr int PF = 2;
+            constexpr int PF = 3;
             const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
             unsigned ba[4][2];
 #pragma unroll
@@ -356,7 +357,8 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             for (int c = 0; c < NCT; ++c) {
                 // in flight when tile c's first MFMA issues: all of c+1 .. c+PF-1, nothing of c+PF yet
                 const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
-                if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 s16x4* k4 = kb[c % (PF + 1)];
