@@ -30,6 +30,22 @@
 #include "common.hpp"
 #include <type_traits>
 
+#ifdef MOMA_K2_STAMPS
+// Diagnostic build only (never the product): per-wave cycle sums of the pipelined loop's phases.
+__device__ unsigned long long moma_k2_stamps[1024 * 4];
+extern "C" int moma_debug_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned long long) * 1024 * 4);
+}
+#define K2_STAMP(var)                                                                     \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#else
+#define K2_STAMP(var) do { } while (0)
+#endif
+
 namespace moma {
 namespace {
 
@@ -131,6 +147,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
+#ifdef MOMA_K2_STAMPS
+    unsigned long long sk0 = 0, sk1 = 0, sk2 = 0, sk3 = 0;
+    K2_STAMP(sk0);
+#endif
 
     // block -> (query tile, key chunk): the nbt tiles of one chunk are 8 block ids apart (same XCD)
     int bt, chunk;
@@ -394,10 +414,16 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // tile t0+1 must have landed before the loop's first score
         wait_tiles_in_flight(min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) > 0 ? min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) : 0);
         __builtin_amdgcn_s_barrier();
+#ifdef MOMA_K2_STAMPS
+        K2_STAMP(sk1);
+#endif
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc1 = 0, acc2 = 0, acc3 = 0, accn = 0;
+        (void)st0; (void)st1; (void)st2; (void)st3; (void)acc1; (void)acc2; (void)acc3; (void)accn;
 #pragma unroll 1
         for (int t = t0; t < t1; ++t) {
             const bool has_next = t + 1 < t1;
             f32x16 xb;
+            K2_STAMP(st0);
             if (has_next) {
                 // slot of tile t-1 (free since the barrier that ended iteration t-1) takes tile t+NBUF-1... which is
                 // tile (t+1)+NBUF-2; with NBUF = 4 the refill target during iteration t is tile t+3 -> slot of t-1
@@ -408,6 +434,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xb[r] = NEG_BIG;
             }
+            K2_STAMP(st1);
             float tmax = NEG_BIG, psum = 0.f;
             pv(slot(t), pa, [&](int c) __attribute__((always_inline)) {
                 if (c < 16) {                                   // xb already holds score - m_ref
@@ -429,13 +456,26 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 l_run += psum;
                 pack(xb, pa);
             }
+            K2_STAMP(st2);
             // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
             {
                 const int newest = min(t + NBUF - 1, t1 - 1);
                 wait_tiles_in_flight(newest - (t + 2) > 0 ? newest - (t + 2) : 0);
             }
             __builtin_amdgcn_s_barrier();
+            K2_STAMP(st3);
+#ifdef MOMA_K2_STAMPS
+            acc1 += st1 - st0; acc2 += st2 - st1; acc3 += st3 - st2; accn += 1;
+#endif
         }
+#ifdef MOMA_K2_STAMPS
+        K2_STAMP(sk2);
+        if (lane == 0) {
+            const int wv = (blockIdx.x * 4 + wave) & 1023;
+            moma_k2_stamps[wv * 4 + 0] = acc1; moma_k2_stamps[wv * 4 + 1] = acc2;
+            moma_k2_stamps[wv * 4 + 2] = sk1 - sk0; moma_k2_stamps[wv * 4 + 3] = sk2 - sk1;
+        }
+#endif
     } else {
         // ---- plain loop (forward-only and repair variants): score, softmax, (P.K), one tile at a time
 #pragma unroll 1
