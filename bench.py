@@ -126,6 +126,26 @@ class KernelEvents:
         return tot / len(self.pairs)
 
 
+def k2_pmc_traffic():
+    """HBM bytes per launch of the one-pass kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of scripts/bench_k2.py on the bench shape, summarised in profiles/): FETCH_SIZE is doubled per
+    the guide's gfx950 correction.  None when no summary is present."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k2_hbm_traffic.csv"))):
+        fetch = write = None
+        for r in csv.DictReader(open(f)):
+            if "infonce_flash_kernel<512, true, false>" in r["kernel"]:
+                if r["counter"] == "FETCH_SIZE":
+                    fetch = float(r["mean_per_launch"])
+                if r["counter"] == "WRITE_SIZE":
+                    write = float(r["mean_per_launch"])
+        if fetch is not None and write is not None:
+            best = int((2 * fetch + write) * 1024)
+    return best
+
+
 def k2_algorithmic(B, d, K, qbytes):
     """one queue read + q,k in + dq out + lse/loss/top1; flops = scores + P.Keys."""
     bytes_ = K * d * qbytes + 3 * B * d * 4 + B * d * 4 + 12 * B
@@ -225,10 +245,13 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MoMA hot path is a HIP library (no CPU fallback)")
+    # rehearsal knobs (never set by the driver): run N ranks on ONE GPU with gloo to exercise the N>1 code path
+    if os.environ.get("MOMA_BENCH_SAME_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl")              # RCCL over xGMI
+        dist.init_process_group(os.environ.get("MOMA_BENCH_BACKEND", "nccl"))     # "nccl" = RCCL over xGMI
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
 
     from moma_amd import ops
@@ -243,6 +266,7 @@ def main():
     trainer = ContrastTrainer(opt)
     if world > 1:
         ddp_s = nn.parallel.DistributedDataParallel(model_s, device_ids=[local], gradient_as_bucket_view=True)
+        opt.gpu = local
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()
     ops.set_event_recorder(rec)
@@ -296,6 +320,8 @@ def main():
             ach = bytes_ / (k2_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        if (a.batch_size, d, a.nce_k, a.queue_dtype) == (256, 512, 65536, "bf16"):
+            roof["traffic"] = k2_pmc_traffic()          # bytes per launch (PMC, committed summary)
         roof.update({"kernel": "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)",
                      "ms_per_launch": round(k2_ms, 4), "whole_call_ms": round(k2_call_ms, 4),
                      "algorithmic_bytes": bytes_, "algorithmic_flops": flops,
