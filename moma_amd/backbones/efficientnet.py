@@ -34,6 +34,32 @@ _B0_STAGES = [
 _BN_MOM, _BN_EPS = 0.01, 1e-3
 
 
+class _DepthwiseNative(torch.autograd.Function):
+    """Depthwise conv2d on ATen's own kernels in BOTH directions.  `cudnn.flags(enabled=False)` around the forward
+    alone is not enough: autograd picks the backend again at backward time (-> MIOpen's naive_conv_*_bwd, 16 % of
+    the train step), so the backward is issued here under the same flag."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, groups):
+        w = w.to(x.dtype)
+        with torch.backends.cudnn.flags(enabled=False):
+            y = F.conv2d(x, w, None, stride, padding, 1, groups)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, groups = ctx.cfg
+        pad = padding if isinstance(padding, (tuple, list)) else (padding, padding)
+        with torch.backends.cudnn.flags(enabled=False):
+            gx, gw, _ = torch.ops.aten.convolution_backward(
+                gy.contiguous(), x, w, None, list(stride), list(pad), [1, 1], False, [0, 0], groups,
+                [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, (gw.float() if gw is not None else None), None, None, None
+
+
 class SamePadConv2d(nn.Conv2d):
     """Conv2d with TensorFlow 'SAME' padding computed from the input size at call time."""
 
@@ -50,9 +76,10 @@ class SamePadConv2d(nn.Conv2d):
         if ph % 2 or pw % 2:
             x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
             pad = 0
-        if _DW_NATIVE and self.groups > 1 and self.groups == self.in_channels and x.is_cuda:
-            with torch.backends.cudnn.flags(enabled=False):
-                return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
+        if _DW_NATIVE and self.groups > 1 and self.groups == self.in_channels and x.is_cuda and self.bias is None:
+            if torch.is_autocast_enabled():
+                x = x.to(torch.get_autocast_gpu_dtype())
+            return _DepthwiseNative.apply(x, self.weight, self.stride, pad, self.groups)
         return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
 
 
