@@ -102,12 +102,82 @@ class MoCo(BaseMoCo):
         return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
 
 
+class _DualQueue(BaseMoCo):
+    """Two queues (`memory_s`, `memory_t`) sharing one pointer -- base of MoCoST / MoCoSSTT
+    (reference MoMA/mem_moco.py:165-253).  Same RNG consumption and normalisation as the reference."""
+
+    def __init__(self, n_dim, K=65536, T=0.07, queue_dtype=torch.float32, precision="fp32"):
+        super().__init__(K, T, precision)
+        self.register_buffer("memory_s", torch.randn(K, n_dim))
+        self.register_buffer("memory_t", torch.randn(K, n_dim))
+        self.memory_s = F.normalize(self.memory_s)
+        self.memory_t = F.normalize(self.memory_t)
+        if queue_dtype != torch.float32:
+            self.memory_s = self.memory_s.to(queue_dtype)
+            self.memory_t = self.memory_t.to(queue_dtype)
+
+    def _snap(self, mem, *qs):
+        need = torch.is_grad_enabled() and any(q is not None and q.requires_grad for q in qs)
+        return mem.clone().detach() if need else mem
+
+    def _enqueue_both(self, k, k_t, all_k, all_k_t):
+        all_k = all_k if all_k is not None else k
+        all_k_t = all_k_t if all_k_t is not None else k_t
+        self._update_memory(all_k, self.memory_s)
+        self._update_memory(all_k_t, self.memory_t)
+        self._update_pointer(all_k.size(0))
+
+
+class MoCoST(_DualQueue):
+    """student / teacher queues: logits of q against (k, memory_s) and (k_t, memory_t)   (reference :165-201)"""
+
+    def forward(self, q, k, k_t, all_k=None, all_k_t=None):
+        k, k_t = k.detach(), k_t.detach()
+        queue_s, queue_t = self._snap(self.memory_s, q), self._snap(self.memory_t, q)
+        logits_ss = self._compute_logit(q, k, queue_s)
+        logits_st = self._compute_logit(q, k_t, queue_t)
+        labels = torch.zeros(q.size(0), dtype=torch.long, device=q.device)
+        self._enqueue_both(k, k_t, all_k, all_k_t)
+        return logits_ss, logits_st, labels
+
+    def forward_fused(self, q, k, k_t, all_k=None, all_k_t=None):
+        """-> ((loss_ss, loss_st), (acc_ss, acc_st)): each InfoNCE term in one pass over its queue."""
+        k, k_t = k.detach(), k_t.detach()
+        l_ss, _, t_ss = ops.infonce_fused(q, k, self.memory_s, self.T, self.precision)
+        l_st, _, t_st = ops.infonce_fused(q, k_t, self.memory_t, self.T, self.precision)
+        self._enqueue_both(k, k_t, all_k, all_k_t)
+        acc = lambda t: t.float().mean(0, keepdim=True) * 100.0
+        return (l_ss.mean(), l_st.mean()), (acc(t_ss), acc(t_st))
+
+
+class MoCoSSTT(_DualQueue):
+    """four-way variant: optional teacher query q_t adds logits_ts / logits_tt   (reference :205-253)"""
+
+    def forward(self, q, k, q_t=None, k_t=None, all_k=None, all_k_t=None):
+        k, k_t = k.detach(), k_t.detach()
+        queue_s, queue_t = self._snap(self.memory_s, q, q_t), self._snap(self.memory_t, q, q_t)
+        logits_ss = self._compute_logit(q, k, queue_s)
+        logits_st = self._compute_logit(q, k_t, queue_t)
+        if q_t is not None:
+            logits_ts = self._compute_logit(q_t, k, queue_s)
+            logits_tt = self._compute_logit(q_t, k_t, queue_t)
+        labels = torch.zeros(q.size(0), dtype=torch.long, device=q.device)
+        self._enqueue_both(k, k_t, all_k, all_k_t)
+        if q_t is not None:
+            return logits_ss, logits_st, logits_ts, logits_tt, labels
+        return logits_ss, logits_st, labels
+
+
 def build_mem(opt):
     """Factory on opt.mem (reference MoMA/mem_moco.py:256-272).  Extra, optional opt fields:
     `moma_prec` ('fp32' | 'bf16') and `queue_dtype` ('fp32' | 'bf16')."""
     prec = getattr(opt, "moma_prec", "fp32")
     qdt = {"fp32": torch.float32, "bf16": torch.bfloat16}[getattr(opt, "queue_dtype", "fp32")]
-    if opt.mem in ("MoCoSSTT", "MoCoST", "MoCoAtt"):
-        # dual-queue / cross-attention memories: SURVEY section 8(f) rows n1/n2, not on the --distill moma loop
+    if opt.mem == "MoCoSSTT":
+        return MoCoSSTT(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)
+    if opt.mem == "MoCoST":
+        return MoCoST(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)
+    if opt.mem == "MoCoAtt":
+        # cross-attention memory: SURVEY section 8(f) row n1, not reachable from the --distill moma loop
         raise NotImplementedError("mem not built yet: {}".format(opt.mem))
     return MoCo(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)   # reference default branch

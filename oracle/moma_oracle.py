@@ -198,3 +198,20 @@ def distill_kl(y_s, y_t, T):
     lt = lt - np.log(np.exp(lt).sum(1, keepdims=True))
     pt = np.exp(lt)
     return float((pt * (lt - ls)).sum() / y_s.shape[0] * T * T)
+
+
+# --------------------------------------------------------------------------------------------------
+# MoMA/mem_moco.py:165-253  MoCoST / MoCoSSTT: two queues sharing one pointer; logits of q (and optionally q_t)
+# against (k, memory_s) and (k_t, memory_t) from the PRE-enqueue queues, then both queues are enqueued.
+# --------------------------------------------------------------------------------------------------
+def moco_dual_forward(mem_s, mem_t, index, q, k, k_t, T, q_t=None, all_k=None, all_k_t=None):
+    K = mem_s.shape[0]
+    qs, qt = mem_s.copy(), mem_t.copy()
+    outs = [compute_logit(q, k, qs, T), compute_logit(q, k_t, qt, T)]
+    if q_t is not None:
+        outs += [compute_logit(q_t, k, qs, T), compute_logit(q_t, k_t, qt, T)]
+    all_k = k if all_k is None else all_k
+    all_k_t = k_t if all_k_t is None else all_k_t
+    update_memory(mem_s, all_k, index)
+    update_memory(mem_t, all_k_t, index)
+    return outs, np.zeros(q.shape[0], dtype=np.int64), update_pointer(index, all_k.shape[0], K)

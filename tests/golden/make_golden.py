@@ -12,6 +12,7 @@ What is captured:
   G3 ema         learning/contrast_trainer.py:207-211 momentum_update on a ragged tensor list
   G4 infonce     MoCo.forward + nn.CrossEntropyLoss   loss, dq, top-1 accuracy
   G5 step trace  helper/loops_moma.py:221-373         10 steps of train_distill_moma (resnet8 pair)
+  G6 dual queue  MoMA/mem_moco.py:165-253             MoCoST / MoCoSSTT logits, queues, pointer
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -159,6 +160,31 @@ def g4_infonce():
     np.savez_compressed(os.path.join(OUT, "g4_infonce.npz"), **out)
 
 
+def g6_dual_queue():
+    """MoCoST / MoCoSSTT (MoMA/mem_moco.py:165-253): logits, labels, both queues and the pointer over 3 steps."""
+    from MoMA.mem_moco import MoCoST, MoCoSSTT
+    out = {}
+    K, d, B = 48, 16, 10
+    for ci, cls in enumerate([MoCoST, MoCoSSTT]):
+        torch.manual_seed(6000 + ci)
+        mem = cls(d, K, 0.15)
+        p = f"c{ci}_"
+        out[p + "cfg"] = np.array([K, d, B], dtype=np.int64)
+        out[p + "ms0"] = mem.memory_s.numpy().copy(); out[p + "mt0"] = mem.memory_t.numpy().copy()
+        for s in range(3):
+            q, k, kt, qt = [torch.randn(B, d) for _ in range(4)]
+            if cls is MoCoST:
+                res = mem(q, k, kt)
+            else:
+                res = mem(q, k, q_t=qt, k_t=kt)
+            for j, t in enumerate(res[:-1]):
+                out[p + f"s{s}_logits{j}"] = t.numpy().copy()
+            out[p + f"s{s}_q"] = q.numpy(); out[p + f"s{s}_k"] = k.numpy(); out[p + f"s{s}_kt"] = kt.numpy(); out[p + f"s{s}_qt"] = qt.numpy()
+            out[p + f"s{s}_ms"] = mem.memory_s.numpy().copy(); out[p + f"s{s}_mt"] = mem.memory_t.numpy().copy()
+            out[p + f"s{s}_index"] = np.array(mem.index)
+    np.savez_compressed(os.path.join(OUT, "g6_dual_queue.npz"), **out)
+
+
 def g5_step_trace():
     """10 steps of the reference loop, resnet8 student/teacher (same arch so the zip-EMA is defined,
     SURVEY Q4), B=8, 32x32, n_cls=100, K=64, head in {None, mlp}, -c 1 -d 1 -b 1, attn=self."""
@@ -285,12 +311,13 @@ def g5_step_trace():
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
     if "g4" in which: g4_infonce()
     if "g5" in which: g5_step_trace()
+    if "g6" in which: g6_dual_queue()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

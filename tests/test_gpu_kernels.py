@@ -308,3 +308,30 @@ def test_moco_fp32_storage_uses_bf16_mirror(ops):
     q = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
     m32.forward_fused(q, q)
     assert torch.equal(m32._shadow[B:], m32.memory.to(torch.bfloat16)[B:])
+
+
+def test_dual_queue_memories_golden(ops, golden_dir):
+    """MoCoST / MoCoSSTT (reference MoMA/mem_moco.py:165-253): logits vs the reference, queues + pointer bit-exact."""
+    from moma_amd.MoMA.mem_moco import MoCoST, MoCoSSTT
+    g = _g(golden_dir, "g6_dual_queue.npz")
+    for ci, cls in enumerate([MoCoST, MoCoSSTT]):
+        p = f"c{ci}_"
+        K, d, B = [int(v) for v in g[p + "cfg"]]
+        mem = cls(d, K, 0.15).cuda()
+        mem.memory_s.copy_(_t(g[p + "ms0"])); mem.memory_t.copy_(_t(g[p + "mt0"]))
+        for s in range(3):
+            q, k, kt, qt = [_t(g[p + f"s{s}_{nm}"]) for nm in ("q", "k", "kt", "qt")]
+            res = mem(q, k, kt) if cls is MoCoST else mem(q, k, q_t=qt, k_t=kt)
+            assert len(res) == (3 if cls is MoCoST else 5) and res[-1].dtype == torch.long and int(res[-1].sum()) == 0
+            for j, t in enumerate(res[:-1]):
+                np.testing.assert_allclose(t.cpu().numpy(), g[p + f"s{s}_logits{j}"], rtol=2e-5, atol=2e-5)
+            assert np.array_equal(mem.memory_s.cpu().numpy(), g[p + f"s{s}_ms"])
+            assert np.array_equal(mem.memory_t.cpu().numpy(), g[p + f"s{s}_mt"])
+            assert mem.index == int(g[p + f"s{s}_index"])
+    # fused form: two one-pass terms, gradient flows to q
+    mem = MoCoST(64, 512, 0.15).cuda()
+    q = torch.nn.functional.normalize(torch.randn(8, 64, device="cuda")).requires_grad_(True)
+    k = torch.nn.functional.normalize(torch.randn(8, 64, device="cuda"))
+    (l1, l2), _ = mem.forward_fused(q, k, k.flip(0))
+    (l1 + l2).backward()
+    assert torch.isfinite(q.grad).all() and mem.index == 8
