@@ -96,6 +96,12 @@ int moma_infonce_logits(const float* q, const float* k, const void* queue, float
 int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* queue, float* dq,
                             int B, int d, int K, float inv_T, int qdtype, int prec,
                             moma_stream_t stream);
+/* gradients of the logits w.r.t. the key / queue operands (needed by the MoCoAtt cross-attention variants,
+ * MoMA/mem_moco.py:103-161, where k and the queue are attention outputs that carry gradient):
+ *     dk[b,:]     = dlogits[b,0] * q_b * inv_T                          (may be NULL)
+ *     dqueue[j,:] = sum_b dlogits[b,1+j] * q_b * inv_T   ([K,d] fp32)    (may be NULL) */
+int moma_infonce_logits_bwd_kq(const float* dlogits, const float* q, float* dk, float* dqueue,
+                               int B, int d, int K, float inv_T, int prec, moma_stream_t stream);
 size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec);
 int moma_infonce_fused(const float* q, const float* k, const void* queue, int B, int d, int K,
                        float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,

@@ -102,6 +102,63 @@ class MoCo(BaseMoCo):
         return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
 
 
+class MoCoAtt(BaseMoCo):
+    """MoCo cache whose forward applies the teacher-student CROSS-attention variants before the logits
+    (reference MoMA/mem_moco.py:103-161).  `criterion_kd` is the CMO instance holding the Attention modules
+    (K1, HIP); `attn` selects the variant:
+      'qk'      one module over the 2B tokens [q ; k]                      'self_qk' separate modules on q and k
+      'dual2'   atts_p over [q ; k] -> q, atts_n over [k ; q] -> k, positive logit only
+      'all'     one module over [q ; k ; queue]      'dual'  atts_p over [q ; queue], atts_n over [k ; queue]
+      default   atts_q(q), atts_k(k), atts_queue(queue)
+    The variants that attend over the queue materialise [H, N, N] scores with N = K (+B / +2B), exactly like the
+    reference, so they are only usable with small K."""
+
+    def __init__(self, n_dim, K=65536, T=0.07, mem_name="memory", queue_dtype=torch.float32, precision="fp32"):
+        super().__init__(K, T, precision)
+        self.register_buffer(mem_name, torch.randn(K, n_dim))
+        self.memory = F.normalize(self.memory)
+
+    def _compute_logit_qk(self, q, k):
+        """positive logit only (reference :51-66); [B] after the reference's squeeze"""
+        return ((q * k).sum(dim=1) / self.T).contiguous()
+
+    def forward(self, q, k, all_k=None, attn=None, criterion_kd=None):
+        bsz = q.size(0)
+        k = k.detach()
+        queue = self.memory.clone().detach()
+        cat = lambda *ts: torch.cat([t.float() for t in ts], dim=0)
+        if attn == "all":
+            out = criterion_kd.atts(cat(q, k, queue))
+            q, k, queue = out[:bsz], out[bsz:2 * bsz], out[2 * bsz:]
+        elif attn == "qk":
+            out = criterion_kd.atts(cat(q, k))
+            q, k = out[:bsz], out[bsz:]
+        elif attn == "dual":
+            out_p = criterion_kd.atts_p(cat(q, queue))
+            q, queue = out_p[:bsz], out_p[bsz:]
+            out_n = criterion_kd.atts_n(cat(k, queue))
+            k, queue = out_n[:bsz], out_n[bsz:]
+        elif attn == "dual2":
+            q = criterion_kd.atts_p(cat(q, k))[:bsz]
+            k = criterion_kd.atts_n(cat(k, q))[:bsz]
+        elif attn in ("self_qk", "self_qkv2"):
+            q = criterion_kd.atts_q(q)
+            k = criterion_kd.atts_k(k)
+        else:
+            q = criterion_kd.atts_q(q)
+            k = criterion_kd.atts_k(k)
+            queue = criterion_kd.atts_queue(queue)
+        if attn == "dual2":
+            logits = self._compute_logit_qk(q, k)
+        else:
+            logits = self._compute_logit(q.contiguous(), k.contiguous(), queue.contiguous())
+        labels = torch.zeros(bsz, dtype=torch.long, device=q.device)
+        all_k = all_k if all_k is not None else k
+        self._update_memory(all_k, self.memory)
+        self._update_pointer(all_k.size(0))
+        return logits, labels
+
+
 class _DualQueue(BaseMoCo):
     """Two queues (`memory_s`, `memory_t`) sharing one pointer -- base of MoCoST / MoCoSSTT
     (reference MoMA/mem_moco.py:165-253).  Same RNG consumption and normalisation as the reference."""
@@ -178,6 +235,5 @@ def build_mem(opt):
     if opt.mem == "MoCoST":
         return MoCoST(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)
     if opt.mem == "MoCoAtt":
-        # cross-attention memory: SURVEY section 8(f) row n1, not reachable from the --distill moma loop
-        raise NotImplementedError("mem not built yet: {}".format(opt.mem))
+        return MoCoAtt(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)
     return MoCo(opt.feat_dim, opt.nce_k, opt.nce_t, queue_dtype=qdt, precision=prec)   # reference default branch

@@ -30,6 +30,7 @@ SIGNATURES = {
     "moma_enqueue": (_i, [_p, _p, _i, _l, _i, _i, _i, _p]),
     "moma_infonce_logits": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "moma_infonce_logits_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
+    "moma_infonce_logits_bwd_kq": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "moma_infonce_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),

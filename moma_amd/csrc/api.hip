@@ -97,6 +97,22 @@ int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* qu
     return hip_rc(launch_gemm(g, st));
 }
 
+int moma_infonce_logits_bwd_kq(const float* dlogits, const float* q, float* dk, float* dqueue, int B, int d, int K,
+                               float inv_T, int prec, moma_stream_t stream) {
+    if (!dlogits || !q) return MOMA_E_NULL;
+    if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_prec(prec)) return MOMA_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long ld = (long)K + 1;
+    if (dk) MOMA_TRY(launch_pos_grad_init(dlogits, ld, q, dk, B, d, inv_T, st));
+    if (dqueue) {
+        // dqueue[j,c] = sum_b dlogits[b,1+j] * q[b,c]
+        GemmArgs g = gemm(dlogits + 1, q, dqueue, K, d, B, ld, d, d, 1, 1, inv_T, prec);
+        MOMA_TRY(launch_gemm(g, st));
+    }
+    return MOMA_OK;
+}
+
 size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec) {
     if (B <= 0 || d <= 0 || K <= 0) return 0;
     if (infonce_flash_supported(B, d, K, qdtype, prec)) return infonce_flash_workspace_bytes(B, d, K);

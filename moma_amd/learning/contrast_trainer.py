@@ -95,6 +95,46 @@ class ContrastTrainer(BaseTrainer):
         k = node_k[reverse_ids[args.local_rank * bsz:(args.local_rank + 1) * bsz]]
         return k, all_k
 
+    def _shuffle_bn_attn(self, x, model_ema, model_ema_head, criterion_kd, q):
+        """Shuffle-BN key encoding with the attention applied BEFORE the un-shuffle (reference :135-187):
+        attn == 'self_mix' runs one module over [q ; k], otherwise atts_q(q) / atts_k(k).  -> (q, k, all_k).
+        Per-rank (no collectives) unless shuffle_bn == 'gather'."""
+        args = self.args
+        bsz = x.size(0)
+        gather = getattr(args, "shuffle_bn", "per_rank") == "gather" and dist.is_available() and dist.is_initialized()
+        if gather:
+            gp = self.local_group
+            node_x = [torch.ones_like(x) for _ in range(dist.get_world_size(gp))]
+            dist.all_gather(node_x, x.contiguous(), group=gp, async_op=False)
+            node_x = torch.cat(node_x, dim=0)
+            shuffle_ids = torch.randperm(bsz * dist.get_world_size(gp)).to(x.device)
+            reverse_ids = torch.argsort(shuffle_ids)
+            dist.broadcast(shuffle_ids, 0)
+            dist.broadcast(reverse_ids, 0)
+            lo = args.local_rank * bsz
+        else:
+            node_x = x
+            shuffle_ids = torch.randperm(bsz).to(x.device)
+            reverse_ids = torch.argsort(shuffle_ids)
+            lo = 0
+        with torch.no_grad():
+            feat_t, _ = model_ema(node_x[shuffle_ids[lo:lo + bsz]], is_feat=True)
+            k = model_ema_head(feat_t[-1])
+        if args.attn == "self_mix":
+            out = criterion_kd.atts(torch.cat([q, k], dim=0))
+            q, k = out[:bsz], out[bsz:]
+        else:
+            q = criterion_kd.atts_q(q)
+            k = criterion_kd.atts_k(k)
+        if gather:
+            all_k = self._global_gather(k)
+            node_id, ngpus = args.node_rank, args.ngpus_per_node
+            node_k = all_k[node_id * ngpus * bsz:(node_id + 1) * ngpus * bsz]
+        else:
+            all_k = node_k = k
+        k = node_k[reverse_ids[lo:lo + bsz]]
+        return q, k, all_k
+
     # -- loss helper ------------------------------------------------------------------------------
     @staticmethod
     def _compute_loss_accuracy(logits, target, criterion):

@@ -176,22 +176,34 @@ class _InfoNCELogits(torch.autograd.Function):
         out = torch.empty(B, K + 1, device=q.device, dtype=torch.float32)
         check(lib.moma_infonce_logits(_ptr(q), _ptr(k), _ptr(queue), _ptr(out), B, d, K, float(1.0 / T),
                                       _qdtype(queue), prec, _stream()), "moma_infonce_logits")
-        ctx.save_for_backward(k, queue)
+        ctx.save_for_backward(q, k, queue)
         ctx.T, ctx.prec = T, prec
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
         lib = _lib.load()
-        k, queue = ctx.saved_tensors
+        q, k, queue = ctx.saved_tensors
         dlogits = dlogits.contiguous()
         B, d = k.shape
         K = queue.shape[0]
-        dq = torch.empty(B, d, device=k.device, dtype=torch.float32)
-        check(lib.moma_infonce_logits_bwd(_ptr(dlogits), _ptr(k), _ptr(queue), _ptr(dq), B, d, K,
-                                          float(1.0 / ctx.T), _qdtype(queue), ctx.prec, _stream()),
-              "moma_infonce_logits_bwd")
-        return dq, None, None, None, None
+        dq = dk = dqueue = None
+        if ctx.needs_input_grad[0]:
+            dq = torch.empty(B, d, device=k.device, dtype=torch.float32)
+            check(lib.moma_infonce_logits_bwd(_ptr(dlogits), _ptr(k), _ptr(queue), _ptr(dq), B, d, K,
+                                              float(1.0 / ctx.T), _qdtype(queue), ctx.prec, _stream()),
+                  "moma_infonce_logits_bwd")
+        # k / queue carry gradient only in the MoCoAtt cross-attention variants (they are attention outputs there)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            if ctx.needs_input_grad[1]:
+                dk = torch.empty(B, d, device=k.device, dtype=torch.float32)
+            if ctx.needs_input_grad[2]:
+                if queue.dtype != torch.float32:
+                    raise TypeError("a queue that requires grad must be float32")
+                dqueue = torch.empty(K, d, device=k.device, dtype=torch.float32)
+            check(lib.moma_infonce_logits_bwd_kq(_ptr(dlogits), _ptr(q), _ptr(dk), _ptr(dqueue), B, d, K,
+                                                 float(1.0 / ctx.T), ctx.prec, _stream()), "moma_infonce_logits_bwd_kq")
+        return dq, dk, dqueue, None, None
 
 
 def infonce_logits(q, k, queue, T: float, prec="fp32") -> torch.Tensor:

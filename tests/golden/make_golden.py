@@ -13,6 +13,7 @@ What is captured:
   G4 infonce     MoCo.forward + nn.CrossEntropyLoss   loss, dq, top-1 accuracy
   G5 step trace  helper/loops_moma.py:221-373         10 steps of train_distill_moma (resnet8 pair)
   G6 dual queue  MoMA/mem_moco.py:165-253             MoCoST / MoCoSSTT logits, queues, pointer
+  G7 MoCoAtt     MoMA/mem_moco.py:103-161             cross-attention variants: logits, dq, queue
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -185,6 +186,36 @@ def g6_dual_queue():
     np.savez_compressed(os.path.join(OUT, "g6_dual_queue.npz"), **out)
 
 
+def g7_mocoatt():
+    """MoCoAtt.forward cross-attention variants (MoMA/mem_moco.py:103-161) with the CMO attention modules."""
+    import argparse
+    from MoMA.mem_moco import MoCoAtt
+    from MoMA.criterion_moco_att import CMO
+    out = {}
+    K, d, B = 24, 32, 6
+    variants = [("qk", "qk"), ("dual2", "dual2"), ("self_qk", "self_qk"), ("all", "all"), ("dual", "dual"), ("self", "self")]
+    for ci, (cmo_attn, fw_attn) in enumerate(variants):
+        torch.manual_seed(7000 + ci)
+        opt = argparse.Namespace(head="None", s_dim=d, t_dim=d, feat_dim=d, attn=cmo_attn)
+        kd = CMO(opt)
+        mem = MoCoAtt(d, K, 0.15)
+        p = f"c{ci}_"
+        out[p + "attn"] = np.array(fw_attn)
+        out[p + "mem0"] = mem.memory.numpy().copy()
+        for name, t in kd.state_dict().items():
+            out[p + "kd." + name] = t.numpy().copy()
+        q = torch.nn.functional.normalize(torch.randn(B, d)).requires_grad_(True)
+        k = torch.nn.functional.normalize(torch.randn(B, d))
+        logits, labels = mem(q, k, attn=fw_attn, criterion_kd=kd)
+        w = torch.randn_like(logits)
+        (logits * w).sum().backward()
+        out[p + "q"] = q.detach().numpy(); out[p + "k"] = k.numpy(); out[p + "w"] = w.numpy()
+        out[p + "logits"] = logits.detach().numpy(); out[p + "dq"] = q.grad.numpy()
+        out[p + "mem1"] = mem.memory.numpy().copy(); out[p + "index"] = np.array(mem.index)
+    out["n_cases"] = np.array(len(variants))
+    np.savez_compressed(os.path.join(OUT, "g7_mocoatt.npz"), **out)
+
+
 def g5_step_trace():
     """10 steps of the reference loop, resnet8 student/teacher (same arch so the zip-EMA is defined,
     SURVEY Q4), B=8, 32x32, n_cls=100, K=64, head in {None, mlp}, -c 1 -d 1 -b 1, attn=self."""
@@ -311,13 +342,14 @@ def g5_step_trace():
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
     if "g4" in which: g4_infonce()
     if "g5" in which: g5_step_trace()
     if "g6" in which: g6_dual_queue()
+    if "g7" in which: g7_mocoatt()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

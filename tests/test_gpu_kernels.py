@@ -335,3 +335,31 @@ def test_dual_queue_memories_golden(ops, golden_dir):
     (l1, l2), _ = mem.forward_fused(q, k, k.flip(0))
     (l1 + l2).backward()
     assert torch.isfinite(q.grad).all() and mem.index == 8
+
+
+def test_mocoatt_cross_attention_variants_golden(ops, golden_dir):
+    """MoCoAtt.forward (reference MoMA/mem_moco.py:103-161): every attn variant against vectors from the reference --
+    logits, gradient w.r.t. the student query through the attention modules, enqueued queue, pointer."""
+    import argparse
+    from moma_amd.MoMA.mem_moco import MoCoAtt
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    g = _g(golden_dir, "g7_mocoatt.npz")
+    K, d, B = 24, 32, 6
+    cmo_attn = ["qk", "dual2", "self_qk", "all", "dual", "self"]
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        fw_attn = str(g[p + "attn"])
+        opt = argparse.Namespace(head="None", s_dim=d, t_dim=d, feat_dim=d, attn=cmo_attn[ci], moma_prec="fp32")
+        kd = CMO(opt)
+        kd.load_state_dict({k[len(p) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(p + "kd.")})
+        kd = kd.cuda()
+        mem = MoCoAtt(d, K, 0.15).cuda()
+        mem.memory.copy_(_t(g[p + "mem0"]))
+        q = _t(g[p + "q"]).requires_grad_(True)
+        logits, labels = mem(q, _t(g[p + "k"]), attn=fw_attn, criterion_kd=kd)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g[p + "logits"], rtol=2e-4, atol=2e-4, err_msg=fw_attn)
+        (logits * _t(g[p + "w"])).sum().backward()
+        ref = g[p + "dq"]
+        np.testing.assert_allclose(q.grad.cpu().numpy(), ref, rtol=0, atol=3e-4 * max(1.0, np.abs(ref).max()), err_msg=fw_attn)
+        np.testing.assert_allclose(mem.memory.cpu().numpy(), g[p + "mem1"], rtol=0, atol=2e-5, err_msg=fw_attn)
+        assert mem.index == int(g[p + "index"]) and int(labels.sum()) == 0
