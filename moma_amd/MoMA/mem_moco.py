@@ -32,6 +32,14 @@ class BaseMoCo(nn.Module):
     def _update_pointer(self, bsz):
         self.index = (self.index + bsz) % self.K
 
+    # The reference never checkpoints the queue or its pointer; here the pointer rides along in the
+    # state_dict as extra state so that a resumed run continues the ring buffer where it stopped.
+    def get_extra_state(self):
+        return {"index": int(self.index)}
+
+    def set_extra_state(self, state):
+        self.index = int(state.get("index", 0)) % self.K
+
     def _update_memory(self, k, queue):
         """queue[(index + i) mod K] = k[i]   (reference :17-27)"""
         with torch.no_grad():

@@ -113,6 +113,8 @@ def build_parser():
     p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic loader length")
     p.add_argument("--num_heads", type=int, default=4)
     p.add_argument("--save_root", type=str, default="./save")
+    p.add_argument("--resume", type=str, default=None,
+                   help="checkpoint written by this trainer (ckpt_last.pth): student, EMA teacher, CMO, queue + pointer, optimizer")
     return p
 
 
@@ -234,7 +236,19 @@ def main_worker(gpu, ngpus_per_node, opt):
         os.makedirs(opt.save_folder, exist_ok=True)
         trainer.args.tb_folder = opt.tb_folder
     best_acc, t_total = 0.0, time.time()
-    for epoch in range(1, opt.epochs + 1):
+    start_epoch = 1
+    if opt.resume:
+        ck = torch.load(opt.resume, map_location=device)
+        model_s.load_state_dict(ck["model"])
+        model_t.load_state_dict(ck["model_t"])
+        criterion_list[2].load_state_dict(ck["criterion_kd"])
+        if contrast is not None and ck.get("contrast") is not None:
+            contrast.load_state_dict(ck["contrast"])
+        optimizer.load_state_dict(ck["optimizer"])
+        best_acc, start_epoch = ck.get("best_acc", 0.0), ck["epoch"] + 1
+        print("==> resumed from {} (epoch {}, queue pointer {})".format(
+            opt.resume, ck["epoch"], contrast.index if contrast is not None else "-"))
+    for epoch in range(start_epoch, opt.epochs + 1):
         adjust_learning_rate(epoch, opt, optimizer)
         print("==> training...")
         t1 = time.time()
@@ -257,6 +271,12 @@ def main_worker(gpu, ngpus_per_node, opt):
                 state = {"epoch": epoch, "model": model_s.state_dict(), "best_acc": best_acc,
                          "best_acc_epoch": epoch, "optimizer": optimizer.state_dict()}
                 torch.save(state, os.path.join(opt.save_folder, "net_best_acc.pth"))
+            # full training state (the reference saves the student only): enough to resume bit-for-bit
+            torch.save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
+                        "criterion_kd": criterion_list[2].state_dict(),
+                        "contrast": contrast.state_dict() if contrast is not None else None,
+                        "optimizer": optimizer.state_dict(), "best_acc": best_acc},
+                       os.path.join(opt.save_folder, "ckpt_last.pth"))
     if is_main:
         print("best accuracy:", best_acc)
         save_state = {k: v for k, v in vars(opt).items() if not k.startswith("_") and k != "trace"}

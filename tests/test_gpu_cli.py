@@ -27,3 +27,23 @@ def test_cli_trains_on_synthetic(tmp_path, extra):
     assert any(f.endswith("net_best_acc.pth") for f in saved)
     params = [f for f in saved if f.endswith("parameters.json")]
     assert params and json.load(open(params[0]))["nce_t"] == 0.15       # forced for --distill moma (reference :135)
+
+
+def test_cli_resume_continues_queue_pointer(tmp_path):
+    """the trainer's own checkpoint carries queue + pointer + CMO + EMA teacher; --resume continues."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    base = [sys.executable, os.path.join(ROOT, "train_student_moma.py"), "--distill", "moma", "--model_s", "resnet8x4",
+            "--model_t", "resnet8x4", "--dataset", "cifar100", "--n_cls", "2", "--batch_size", "32", "--steps_per_epoch", "5",
+            "--nce_k", "1024", "--head", "mlp", "--feat_dim", "128", "-c", "1", "-d", "1", "-b", "1", "--save_root", str(tmp_path)]
+    r = subprocess.run(base + ["--epochs", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt_last.pth"]
+    assert ck
+    state = torch.load(ck[0], map_location="cpu")
+    assert state["contrast"]["_extra_state"]["index"] == (5 * 32) % 1024 and state["epoch"] == 1
+    r = subprocess.run(base + ["--epochs", "2", "--resume", ck[0]], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "resumed from" in r.stdout and "queue pointer 160" in r.stdout
+    state2 = torch.load(ck[0], map_location="cpu")
+    assert state2["epoch"] == 2 and state2["contrast"]["_extra_state"]["index"] == (10 * 32) % 1024
