@@ -122,7 +122,11 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
  *     fwd keeps for backward (caller-owned): qkv [N,3d], probs [H,N,N], attn_out [N,d].
  *     bwd writes dx [N,d], dw_qkv [3d,d], db_qkv [3d], dw_proj [d,d], db_proj [d]; any of the five may
  *     be NULL to skip it.  bwd workspace: moma_mha_bwd_workspace_bytes().
+ *     With MOMA_PREC_BF16 and a head dim that is a multiple of 16 and <= 128 the per-head core
+ *     (scores, softmax, context; :159-163) is ONE fused launch; then `probs` is only needed when a backward
+ *     follows and may be NULL (moma_mha_probs_optional() == 1), e.g. for the no-grad key/queue modules.
  * ------------------------------------------------------------------------------------------- */
+int moma_mha_probs_optional(int N, int d, int H, int prec);
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj,
                  const float* b_proj, float* y, float* qkv, float* probs, float* attn_out,
                  int N, int d, int H, int prec, moma_stream_t stream);

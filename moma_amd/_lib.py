@@ -35,6 +35,7 @@ SIGNATURES = {
     "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
     "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "moma_mha_probs_optional": (_i, [_i, _i, _i, _i]),
     "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
 }

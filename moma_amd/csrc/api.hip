@@ -153,9 +153,11 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj, const float* b_proj,
                  float* y, float* qkv, float* probs, float* attn_out, int N, int d, int H, int prec,
                  moma_stream_t stream) {
-    if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !probs || !attn_out) return MOMA_E_NULL;
+    if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !attn_out) return MOMA_E_NULL;
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
     if (bad_prec(prec)) return MOMA_E_DTYPE;
+    const bool fused = mha_core_fused_supported(N, d, H, prec);
+    if (!probs && !fused) return MOMA_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int hd = d / H;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -163,6 +165,13 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
     GemmArgs g = gemm(x, w_qkv, qkv, N, 3 * d, d, d, d, 3L * d, 0, 0, 1.f, prec);
     g.bias = b_qkv;
     MOMA_TRY(launch_gemm(g, st));
+    if (fused) {
+        // one launch per module: scores, softmax and context per head (:159-163), mha_fused.hip
+        MOMA_TRY(launch_mha_core_fwd(qkv, attn_out, probs, N, d, H, st));
+        g = gemm(attn_out, w_proj, y, N, d, d, d, d, d, 0, 0, 1.f, prec);
+        g.bias = b_proj;
+        return hip_rc(launch_gemm(g, st));
+    }
     // per head: S = (q k^T) * scale                          (:159)
     g = gemm(qkv, qkv + d, probs, N, N, hd, 3L * d, 3L * d, N, 0, 0, scale, prec);
     g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
@@ -176,6 +185,10 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
     g = gemm(attn_out, w_proj, y, N, d, d, d, d, d, 0, 0, 1.f, prec);
     g.bias = b_proj;
     return hip_rc(launch_gemm(g, st));
+}
+
+int moma_mha_probs_optional(int N, int d, int H, int prec) {
+    return (N > 0 && d > 0 && H > 0 && d % H == 0 && !bad_prec(prec) && mha_core_fused_supported(N, d, H, prec)) ? 1 : 0;
 }
 
 size_t moma_mha_bwd_workspace_bytes(int N, int d, int H) {

@@ -78,4 +78,8 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 
+// ---- mha_fused.hip (fused per-head attention core, forward) ---------------------------------------
+bool mha_core_fused_supported(int N, int d, int H, int prec);
+hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* probs, int N, int d, int H, hipStream_t st);
+
 }  // namespace moma

@@ -51,6 +51,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     out[c] = s;
 }
 
+// same, 64 columns per block as 16 float4 lanes x 16 row groups: every thread has rows/16 independent loads in
+// flight (the scalar kernel above is one dependent chain of `rows` loads per thread), fixed summation order
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                          int cols, long ld) {
+    __shared__ float4 red[16][16];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cx * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+#pragma unroll 8
+        for (int r = ry; r < rows; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ld + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) {
+            const float4 v = red[g][cx];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + c) = acc;
+    }
+}
+
 // out[b*ld_out] = <q_b, k_b> * inv_T        (MoMA/mem_moco.py:37-38,45)
 __global__ __launch_bounds__(256) void pos_logit_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          float* __restrict__ out, long ld_out, int B, int d,
@@ -128,7 +155,10 @@ hipError_t launch_softmax_bwd_rows(const float* p, float* dp, long rows, int col
     return hipGetLastError();
 }
 hipError_t launch_colsum(const float* x, float* out, int rows, int cols, long ld, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, x, out, rows, cols, ld);
+    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, x, out, rows, cols, ld);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, x, out, rows, cols, ld);
     return hipGetLastError();
 }
 hipError_t launch_pos_logit(const float* q, const float* k, float* out, long ld_out, int B, int d, float inv_T, hipStream_t st) {

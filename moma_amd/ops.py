@@ -256,7 +256,7 @@ def infonce_fused(q, k, queue, T: float, prec="fp32") -> Tuple[torch.Tensor, tor
 # ------------------------------------------------------------------------------------------------
 class _MHA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_qkv, b_qkv, w_proj, b_proj, H, prec):
+    def forward(ctx, x, w_qkv, b_qkv, w_proj, b_proj, H, prec, grad_mode):
         lib = _lib.load()
         x = x.contiguous()
         for t, nm in ((x, "x"), (w_qkv, "qkv.weight"), (w_proj, "proj.weight"), (b_proj, "proj.bias")):
@@ -269,12 +269,15 @@ class _MHA(torch.autograd.Function):
         dev = x.device
         y = torch.empty(N, d, device=dev, dtype=torch.float32)
         qkv = torch.empty(N, 3 * d, device=dev, dtype=torch.float32)
-        probs = torch.empty(H, N, N, device=dev, dtype=torch.float32)
+        need_bwd = grad_mode and any(ctx.needs_input_grad)      # (grad mode is always off inside forward)
+        # the fused per-head core only materialises the probabilities when a backward follows
+        probs = (None if (not need_bwd and lib.moma_mha_probs_optional(N, d, H, prec))
+                 else torch.empty(H, N, N, device=dev, dtype=torch.float32))
         attn_out = torch.empty(N, d, device=dev, dtype=torch.float32)
         with _timed("moma_mha_fwd"):
             check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
                                    _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
-        if any(ctx.needs_input_grad):
+        if need_bwd:
             ctx.save_for_backward(x, w_qkv, w_proj, qkv, probs, attn_out)
         ctx.H, ctx.prec, ctx.has_bqkv = H, prec, b_qkv is not None
         return y
@@ -298,8 +301,8 @@ class _MHA(torch.autograd.Function):
         check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(attn_out), _ptr(dy),
                                _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
                                ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
-        return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None
+        return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None, None
 
 
 def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads: int, prec="fp32") -> torch.Tensor:
-    return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec))
+    return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec), torch.is_grad_enabled())

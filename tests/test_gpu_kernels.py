@@ -262,6 +262,35 @@ def test_mha_vs_oracle(ops, N, d, H, prec):
         assert err < tol, (nm, err)
 
 
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (1, 64, 4), (33, 128, 8), (129, 256, 2), (1000, 512, 4), (77, 192, 4)])
+def test_mha_fused_core_no_grad(ops, N, d, H):
+    """bf16 policy, head dim multiple of 16 and <= 128: the per-head core is one fused launch; without a backward
+    the probabilities are never materialised (probs = NULL at the ABI).  Same result as the grad-mode call (which
+    stores them) and as the oracle."""
+    from moma_amd import _lib
+    assert _lib.load().moma_mha_probs_optional(N, d, H, 1) == 1
+    assert _lib.load().moma_mha_probs_optional(N, d, H, 0) == 0          # exact-fp32 policy keeps the staged path
+    rng = np.random.default_rng(N * 7 + d)
+    x = O.l2_normalize(rng.standard_normal((N, d)).astype(np.float32))
+    bound = 1.0 / np.sqrt(d)
+    # large q/k weights -> peaked softmax rows, so a wrong key <-> value pairing cannot hide behind near-uniform rows
+    w_qkv = rng.uniform(-bound, bound, (3 * d, d)).astype(np.float32) * 6
+    w_qkv[:2 * d] *= 8
+    b_qkv = rng.uniform(-bound, bound, 3 * d).astype(np.float32)
+    w_proj = rng.uniform(-bound, bound, (d, d)).astype(np.float32)
+    b_proj = rng.uniform(-bound, bound, d).astype(np.float32)
+    ref = O.attention_fwd(x, w_qkv, b_qkv, w_proj, b_proj, H, dtype=np.float64)
+    ref_y = ref[0] if isinstance(ref, tuple) else ref
+    tw = [_t(a).requires_grad_(True) for a in (w_qkv, b_qkv, w_proj, b_proj)]
+    with torch.no_grad():
+        y0 = ops.mha(_t(x), *tw, H, "bf16")
+    y1 = ops.mha(_t(x), *tw, H, "bf16")
+    # (the projection GEMM may take the split-K path, whose fp32 atomics are order-dependent in the last bit)
+    assert torch.allclose(y0, y1.detach(), rtol=0, atol=1e-6)
+    err = np.abs(y0.cpu().numpy() - ref_y).max() / np.abs(ref_y).max()
+    assert err < 3e-2, err
+
+
 # ------------------------------------------------------------------------------------------------ ABI
 def test_abi_argument_checks(ops):
     from moma_amd import _lib
