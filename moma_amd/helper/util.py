@@ -78,6 +78,6 @@ def load_pretrained_weights(model, state, strict_flag=True):
         state = state["model"]
     clean = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
     if not strict_flag:
-        for k in ("classifier_.1.weight", "classifier_.1.bias", "fc.weight", "fc.bias"):
+        for k in ("classifier_.1.weight", "classifier_.1.bias", "fc.weight", "fc.bias", "head.weight", "head.bias"):
             clean.pop(k, None)
     return model.load_state_dict(clean, strict=strict_flag)

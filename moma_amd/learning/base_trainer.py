@@ -27,7 +27,8 @@ class BaseTrainer(object):
         a.local_center = a.rank * ngpus_per_node
         if torch.cuda.is_available():
             torch.cuda.set_device(gpu)
-            torch.backends.cudnn.benchmark = True     # MIOpen find-mode on ROCm
+            # MIOpen find mode on ROCm (reference :34); the CLI's --miopen_find off keeps immediate mode
+            torch.backends.cudnn.benchmark = getattr(a, "miopen_find", "on") == "on"
         if a.gpu is not None:
             print("Use GPU: {} for training".format(a.gpu))
         if a.multiprocessing_distributed:

@@ -112,6 +112,9 @@ def build_parser():
     p.add_argument("--no_fused", action="store_true", help="reference call sequence on materialised logits")
     p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic loader length")
     p.add_argument("--num_heads", type=int, default=4)
+    p.add_argument("--miopen_find", default="on", choices=["on", "off"],
+                   help="on = cudnn.benchmark as in the reference (MIOpen find mode: minutes at the first step of a new "
+                        "shape); off = immediate mode with the shipped find-db")
     p.add_argument("--save_root", type=str, default="./save")
     p.add_argument("--resume", type=str, default=None,
                    help="checkpoint written by this trainer (ckpt_last.pth): student, EMA teacher, CMO, queue + pointer, optimizer")
@@ -213,7 +216,7 @@ def main_worker(gpu, ngpus_per_node, opt):
         random.seed(opt.seed)
         torch.manual_seed(opt.seed)
         np.random.seed(opt.seed)
-    torch.backends.cudnn.benchmark = not opt.deterministic or True
+    torch.backends.cudnn.benchmark = opt.miopen_find == "on"          # reference :418 sets it unconditionally
     device = torch.device("cuda", opt.gpu)
     print("opt.n_cls: ", opt.n_cls)
 
