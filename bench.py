@@ -57,7 +57,7 @@ def parse():
                    help="NHWC backbones (MIOpen's depthwise backward is ~7x slower in NHWC on gfx950: off by default)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_batch", type=int, default=16)
-    p.add_argument("--cpu_steps", type=int, default=3)
+    p.add_argument("--cpu_steps", type=int, default=15)    # ~10 s of host work at B=16
     p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
     return p.parse_args()
 

@@ -136,6 +136,28 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
                  float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj, void* workspace,
                  size_t workspace_bytes, int N, int d, int H, int prec, moma_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BN  BatchNorm2d + fused activation on NCHW activations -- the `_swish(_bn(conv(x)))` pairs of the
+ *     backbones inside the step (models/efficientnet_pytorch/model.py:96-102,114; nn.BatchNorm2d
+ *     semantics: batch statistics + running-stat update (momentum, unbiased variance) when
+ *     training != 0, running statistics otherwise).  Not one of the KD-term kernels: an HBM-streaming
+ *     helper for the step's throughput (3 passes forward, 5 backward instead of 5 + 8 unfused).
+ *     x, out, dout, dx: [N, C, HW] contiguous, MOMA_DT_F32 or MOMA_DT_BF16; gamma/beta/running/save: fp32 [C]
+ *     (gamma, beta, running_* may be NULL when training).  act: MOMA_ACT_*.  The backward recomputes the
+ *     pre-activation from x and save_mean/save_invstd (written by the forward, eval mode included).
+ *     workspace >= moma_bn_workspace_bytes(C) for either call.
+ * ------------------------------------------------------------------------------------------- */
+enum { MOMA_ACT_NONE = 0, MOMA_ACT_SILU = 1, MOMA_ACT_RELU = 2 };
+size_t moma_bn_workspace_bytes(int C);
+int moma_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float* save_mean, float* save_invstd, void* workspace,
+                size_t workspace_bytes, int N, int C, int HW, int dtype, int act, int training,
+                float momentum, float eps, moma_stream_t stream);
+int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta,
+                const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
+                void* workspace, size_t workspace_bytes, int N, int C, int HW, int dtype, int act,
+                int training, moma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

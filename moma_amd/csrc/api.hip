@@ -251,4 +251,38 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     return MOMA_OK;
 }
 
+size_t moma_bn_workspace_bytes(int C) { return C > 0 ? align_up(bn_workspace_floats(C) * sizeof(float), 256) : 0; }
+
+static int bn_check(int N, int C, int HW, int dtype, int act, const void* ws, size_t ws_bytes) {
+    if (N <= 0 || C <= 0 || HW <= 0 || (long)N * C > 0x7fffffffL || (long)N * HW > 0x7fffffffL) return MOMA_E_SHAPE;
+    if (dtype != MOMA_DT_F32 && dtype != MOMA_DT_BF16) return MOMA_E_DTYPE;
+    if (act != MOMA_ACT_NONE && act != MOMA_ACT_SILU && act != MOMA_ACT_RELU) return MOMA_E_DTYPE;
+    if (!ws) return MOMA_E_NULL;
+    if (ws_bytes < moma_bn_workspace_bytes(C)) return MOMA_E_WORKSPACE;
+    return MOMA_OK;
+}
+
+int moma_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                int N, int C, int HW, int dtype, int act, int training, float momentum, float eps,
+                moma_stream_t stream) {
+    if (!x || !out) return MOMA_E_NULL;
+    if (!training && (!running_mean || !running_var)) return MOMA_E_NULL;
+    const int rc = bn_check(N, C, HW, dtype, act, workspace, workspace_bytes);
+    if (rc != MOMA_OK) return rc;
+    return hip_rc(launch_bn_fwd(x, out, gamma, beta, running_mean, running_var, save_mean, save_invstd,
+                                (float*)workspace, N, C, HW, dtype, act, training, momentum, eps, (hipStream_t)stream));
+}
+
+int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* save_mean,
+                const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                size_t workspace_bytes, int N, int C, int HW, int dtype, int act, int training,
+                moma_stream_t stream) {
+    if (!x || !dout || !save_mean || !save_invstd) return MOMA_E_NULL;
+    const int rc = bn_check(N, C, HW, dtype, act, workspace, workspace_bytes);
+    if (rc != MOMA_OK) return rc;
+    return hip_rc(launch_bn_bwd(x, dout, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, (float*)workspace, N,
+                                C, HW, dtype, act, training, (hipStream_t)stream));
+}
+
 }  // extern "C"

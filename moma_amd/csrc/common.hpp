@@ -82,4 +82,13 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 bool mha_core_fused_supported(int N, int d, int H, int prec);
 hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* probs, int N, int d, int H, hipStream_t st);
 
+// ---- bn.hip (BatchNorm2d + activation, NCHW) ------------------------------------------------------
+size_t bn_workspace_floats(int C);
+hipError_t launch_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* rm, float* rv,
+                         float* save_mean, float* save_invstd, float* ws, int N, int C, int HW, int dtype, int act,
+                         int training, float momentum, float eps, hipStream_t st);
+hipError_t launch_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, void* dx, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
+                         int dtype, int act, int training, hipStream_t st);
+
 }  // namespace moma

@@ -306,3 +306,56 @@ class _MHA(torch.autograd.Function):
 
 def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads: int, prec="fp32") -> torch.Tensor:
     return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec), torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d + fused activation on NCHW activations (backbone helper, include/moma_hip.h "BN")
+# ------------------------------------------------------------------------------------------------
+ACT_CODES = {None: 0, "none": 0, "silu": 1, "relu": 2}
+_DT_CODES = {torch.float32: 0, torch.bfloat16: 1}
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        lib = _lib.load()
+        _dev(x, "x", dtype=None)
+        if x.dim() < 2 or x.dtype not in _DT_CODES:
+            raise ValueError(f"bn_act: expects [N, C, ...] float32 / bfloat16, got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * Cc)
+        dev = x.device
+        out = torch.empty_like(x)
+        save_mean = torch.empty(Cc, device=dev, dtype=torch.float32)
+        save_invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.moma_bn_workspace_bytes(Cc), device=dev, dtype=torch.uint8)
+        check(lib.moma_bn_fwd(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                              _ptr(save_mean), _ptr(save_invstd), _ptr(ws), ws.numel(), N, Cc, HW, _DT_CODES[x.dtype],
+                              act, int(training), float(momentum), float(eps), _stream()), "moma_bn_fwd")
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        ctx.cfg = (N, Cc, HW, act, int(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        N, Cc, HW, act, training = ctx.cfg
+        dout = dout.contiguous()
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dgamma = torch.empty(Cc, device=dev, dtype=torch.float32) if (weight is not None and ctx.needs_input_grad[1]) else None
+        dbeta = torch.empty(Cc, device=dev, dtype=torch.float32) if (bias is not None and ctx.needs_input_grad[2]) else None
+        ws = torch.empty(lib.moma_bn_workspace_bytes(Cc), device=dev, dtype=torch.uint8)
+        check(lib.moma_bn_bwd(_ptr(x), _ptr(dout), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd), _ptr(dx),
+                              _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), N, Cc, HW, _DT_CODES[x.dtype], act,
+                              training, _stream()), "moma_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float, act=None):
+    """act(batch_norm(x)) on a contiguous NCHW tensor; running statistics are updated in place when training."""
+    return _BNAct.apply(x, weight, bias, running_mean, running_var, bool(training), momentum, eps, ACT_CODES[act])

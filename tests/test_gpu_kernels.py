@@ -285,8 +285,9 @@ def test_mha_fused_core_no_grad(ops, N, d, H):
     with torch.no_grad():
         y0 = ops.mha(_t(x), *tw, H, "bf16")
     y1 = ops.mha(_t(x), *tw, H, "bf16")
-    # (the projection GEMM may take the split-K path, whose fp32 atomics are order-dependent in the last bit)
-    assert torch.allclose(y0, y1.detach(), rtol=0, atol=1e-6)
+    # (the qkv / projection GEMMs may take the split-K path, whose fp32 atomics are order-dependent in the last bits,
+    #  and the peaked softmax amplifies that: agreement to 1e-3 of the output range, not bit equality)
+    assert torch.allclose(y0, y1.detach(), rtol=0, atol=1e-3 * y0.abs().max().item())
     err = np.abs(y0.cpu().numpy() - ref_y).max() / np.abs(ref_y).max()
     assert err < 3e-2, err
 
@@ -392,3 +393,51 @@ def test_mocoatt_cross_attention_variants_golden(ops, golden_dir):
         np.testing.assert_allclose(q.grad.cpu().numpy(), ref, rtol=0, atol=3e-4 * max(1.0, np.abs(ref).max()), err_msg=fw_attn)
         np.testing.assert_allclose(mem.memory.cpu().numpy(), g[p + "mem1"], rtol=0, atol=2e-5, err_msg=fw_attn)
         assert mem.index == int(g[p + "index"]) and int(labels.sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ BN + activation
+def _bn_ref(x, w, b, rm, rv, training, mom, eps, act, dout):
+    """torch reference in fp64 on the (possibly bf16-rounded) input values."""
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    y = torch.nn.functional.batch_norm(xd, rmd, rvd, wd, bd, training, mom, eps)
+    y = torch.nn.functional.silu(y) if act == "silu" else (torch.relu(y) if act == "relu" else y)
+    (y * dout.double()).sum().backward()
+    return y.detach(), xd.grad, wd.grad, bd.grad, rmd, rvd
+
+
+@pytest.mark.parametrize("shape", [(32, 24, 56, 56), (16, 40, 14, 14), (8, 1152, 7, 7), (5, 3, 9, 11), (64, 96, 28, 28)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [None, "silu", "relu"])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_matches_torch(ops, shape, dtype, act, training):
+    """Fused BatchNorm2d + activation (bn.hip) against torch's batch_norm + activation in fp64: output, dx, dgamma,
+    dbeta and the running statistics; vector widths 8 / 4 / 1 (HW = 3136, 196, 49, 99, 784), both dtypes, both modes."""
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + (7 if training else 0))
+    N, Cc = shape[0], shape[1]
+    x = (torch.randn(shape, generator=g) * torch.linspace(0.5, 3.0, Cc).view(1, Cc, 1, 1)
+         + torch.linspace(-2.0, 2.0, Cc).view(1, Cc, 1, 1)).cuda().to(dtype)
+    w = (1.0 + 0.3 * torch.randn(Cc, generator=g)).cuda()
+    b = (0.2 * torch.randn(Cc, generator=g)).cuda()
+    rm = (0.1 * torch.randn(Cc, generator=g)).cuda()
+    rv = (1.0 + 0.2 * torch.rand(Cc, generator=g)).cuda()
+    dout = torch.randn(shape, generator=g).cuda().to(dtype)
+    ref_y, ref_dx, ref_dw, ref_db, ref_rm, ref_rv = _bn_ref(x, w, b, rm, rv, training, 0.01, 1e-3, act, dout)
+    xx = x.clone().requires_grad_(True)
+    ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y = ops.bn_act(xx, ww, bb, rm2, rv2, training, 0.01, 1e-3, act)
+    assert y.dtype == dtype and y.shape == x.shape
+    (y.float() * dout.float()).sum().backward()
+    # fp32: a few ulp of the fp32 pipeline; bf16: one output rounding (2^-9 relative) on top
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (8e-3, 8e-3)
+    torch.testing.assert_close(y.double(), ref_y, rtol=rtol, atol=atol)
+    torch.testing.assert_close(xx.grad.double(), ref_dx, rtol=rtol, atol=atol * max(1.0, ref_dx.abs().max().item()))
+    n_el = x.numel() // Cc
+    torch.testing.assert_close(ww.grad.double(), ref_dw, rtol=1e-4, atol=2e-5 * n_el ** 0.5 * 10)
+    torch.testing.assert_close(bb.grad.double(), ref_db, rtol=1e-4, atol=2e-5 * n_el ** 0.5 * 10)
+    torch.testing.assert_close(rm2.double(), ref_rm, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv2.double(), ref_rv, rtol=1e-5, atol=1e-6)
+    if not training:
+        assert torch.equal(rm2, rm) and torch.equal(rv2, rv)
