@@ -158,6 +158,25 @@ int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float
                 void* workspace, size_t workspace_bytes, int N, int C, int HW, int dtype, int act,
                 int training, moma_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DW  depthwise convolution (groups == channels) on NCHW activations -- the MBConv `_depthwise_conv`
+ *     layers of the backbones inside the step (models/efficientnet_pytorch/model.py:59-64,100; TF "SAME"
+ *     padding, possibly asymmetric: pad_top / pad_left are given, bottom / right follow from OH / OW).
+ *     Like BN a throughput helper for the step, not a KD-term kernel.  K in {3,5}, stride in {1,2}.
+ *       y[n,c,oy,ox] = sum_{ky,kx} w[c,ky,kx] * x[n,c, oy*S+ky-pad_top, ox*S+kx-pad_left]   (zero outside)
+ *     x, dx [N,C,H,W]; y, dy [N,C,OH,OW]: MOMA_DT_F32 or MOMA_DT_BF16;  w, dw [C,K,K] fp32.
+ *     bwd_weight needs workspace >= moma_dwconv_workspace_bytes(C, K).
+ * ------------------------------------------------------------------------------------------- */
+size_t moma_dwconv_workspace_bytes(int C, int K);
+int moma_dwconv_fwd(const void* x, const float* w, void* y, int N, int C, int H, int W, int OH, int OW,
+                    int K, int stride, int pad_top, int pad_left, int dtype, moma_stream_t stream);
+int moma_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int OH,
+                         int OW, int K, int stride, int pad_top, int pad_left, int dtype,
+                         moma_stream_t stream);
+int moma_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace,
+                           size_t workspace_bytes, int N, int C, int H, int W, int OH, int OW, int K,
+                           int stride, int pad_top, int pad_left, int dtype, moma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

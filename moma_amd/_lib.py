@@ -36,6 +36,10 @@ SIGNATURES = {
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
     "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "moma_mha_probs_optional": (_i, [_i, _i, _i, _i]),
+    "moma_dwconv_workspace_bytes": (_z, [_i, _i]),
+    "moma_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
+    "moma_dwconv_bwd_data": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
+    "moma_dwconv_bwd_weight": (_i, [_p, _p, _p, _p, _z] + [_i] * 11 + [_p]),
     "moma_bn_workspace_bytes": (_z, [_i]),
     "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),

@@ -15,12 +15,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 # Which PyTorch-ROCm path the two MIOpen-weak ops take (measured on MI355X, bf16 NCHW, B=256):
-#   depthwise convolutions: MIOpen has no tuned gfx950 solver and falls back to naive_conv_* kernels; ATen's own
-#                           depthwise kernel (used when the cudnn/MIOpen backend is switched off for the call) is faster;
+#   depthwise convolutions: MOMA_DW=hip (default) = the library's LDS-tiled depthwise kernels (dwconv.hip, forward /
+#                           backward-data / backward-weight, SAME padding without a padded copy); "aten" = ATen's own
+#                           depthwise kernels (k*k global loads per output: >50 % of the step); "miopen" = MIOpen, which
+#                           has no tuned gfx950 solver and falls back to naive_conv_* kernels;
 #   batch norm (+ SiLU)   : MOMA_BN=hip (default) = the library's fused BatchNorm+activation kernels (bn.hip: 3 HBM
 #                           passes forward, 5 backward); "miopen" = nn.BatchNorm2d + F.silu (MIOpen's spatial BN runs at
 #                           ~10 % of HBM peak on these shapes); "aten" = ATen's native BN (5 % slower than MIOpen).
-_DW_NATIVE = os.environ.get("MOMA_DW_NATIVE", "1") == "1"
+_DW_MODE = os.environ.get("MOMA_DW", "hip")
 _BN_MODE = os.environ.get("MOMA_BN", "hip")
 
 # (repeats, kernel, stride, expand, cin, cout, se_ratio) -- EfficientNet-B0 stage table
@@ -74,11 +76,19 @@ class SamePadConv2d(nn.Conv2d):
         sh, sw = self.stride
         ph = max((math.ceil(ih / sh) - 1) * sh + kh - ih, 0)
         pw = max((math.ceil(iw / sw) - 1) * sw + kw - iw, 0)
+        depthwise = self.groups > 1 and self.groups == self.in_channels == self.out_channels and self.bias is None
+        if depthwise and x.is_cuda and _DW_MODE == "hip" and kh == kw and sh == sw and self.dilation == (1, 1):
+            from .. import ops
+            if ops.dwconv_supported(kh, sh):
+                if torch.is_autocast_enabled():
+                    x = x.to(torch.get_autocast_gpu_dtype())
+                if x.dtype in (torch.float32, torch.bfloat16):
+                    return ops.dwconv(x, self.weight, sh, ph // 2, pw // 2, math.ceil(ih / sh), math.ceil(iw / sw))
         pad = (ph // 2, pw // 2)
         if ph % 2 or pw % 2:
             x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
             pad = 0
-        if _DW_NATIVE and self.groups > 1 and self.groups == self.in_channels and x.is_cuda and self.bias is None:
+        if depthwise and x.is_cuda and _DW_MODE in ("hip", "aten"):
             if torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_gpu_dtype())
             return _DepthwiseNative.apply(x, self.weight, self.stride, pad, self.groups)

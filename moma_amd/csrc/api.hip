@@ -285,4 +285,45 @@ int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float
                                 C, HW, dtype, act, training, (hipStream_t)stream));
 }
 
+size_t moma_dwconv_workspace_bytes(int C, int K) {
+    return (C > 0 && K > 0) ? align_up(dwconv_workspace_floats(C, K) * sizeof(float), 256) : 0;
+}
+
+static int dw_check(int N, int C, int H, int W, int OH, int OW, int K, int S, int pt, int pl, int dtype) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (long)N * C > 0x7fffffffL) return MOMA_E_SHAPE;
+    if (!dwconv_supported(K, S)) return MOMA_E_SHAPE;
+    if (pt < 0 || pl < 0 || pt >= K || pl >= K) return MOMA_E_SHAPE;
+    // every output must read at least its first tap row/column inside the padded image
+    if ((long)(OH - 1) * S - pt >= H || (long)(OW - 1) * S - pl >= W) return MOMA_E_SHAPE;
+    if (dtype != MOMA_DT_F32 && dtype != MOMA_DT_BF16) return MOMA_E_DTYPE;
+    return MOMA_OK;
+}
+
+int moma_dwconv_fwd(const void* x, const float* w, void* y, int N, int C, int H, int W, int OH, int OW, int K, int stride,
+                    int pad_top, int pad_left, int dtype, moma_stream_t stream) {
+    if (!x || !w || !y) return MOMA_E_NULL;
+    const int rc = dw_check(N, C, H, W, OH, OW, K, stride, pad_top, pad_left, dtype);
+    if (rc != MOMA_OK) return rc;
+    return hip_rc(launch_dw_fwd(x, w, y, N, C, H, W, OH, OW, K, stride, pad_top, pad_left, dtype, (hipStream_t)stream));
+}
+
+int moma_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int OH, int OW, int K,
+                         int stride, int pad_top, int pad_left, int dtype, moma_stream_t stream) {
+    if (!dy || !w || !dx) return MOMA_E_NULL;
+    const int rc = dw_check(N, C, H, W, OH, OW, K, stride, pad_top, pad_left, dtype);
+    if (rc != MOMA_OK) return rc;
+    return hip_rc(launch_dw_bwd_data(dy, w, dx, N, C, H, W, OH, OW, K, stride, pad_top, pad_left, dtype, (hipStream_t)stream));
+}
+
+int moma_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C,
+                           int H, int W, int OH, int OW, int K, int stride, int pad_top, int pad_left, int dtype,
+                           moma_stream_t stream) {
+    if (!x || !dy || !dw || !workspace) return MOMA_E_NULL;
+    const int rc = dw_check(N, C, H, W, OH, OW, K, stride, pad_top, pad_left, dtype);
+    if (rc != MOMA_OK) return rc;
+    if (workspace_bytes < moma_dwconv_workspace_bytes(C, K)) return MOMA_E_WORKSPACE;
+    return hip_rc(launch_dw_bwd_weight(x, dy, dw, (float*)workspace, workspace_bytes / sizeof(float), N, C, H, W, OH, OW, K,
+                                       stride, pad_top, pad_left, dtype, (hipStream_t)stream));
+}
+
 }  // extern "C"

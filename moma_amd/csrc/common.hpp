@@ -91,4 +91,14 @@ hipError_t launch_bn_bwd(const void* x, const void* dout, const float* gamma, co
                          const float* save_invstd, void* dx, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
                          int dtype, int act, int training, hipStream_t st);
 
+// ---- dwconv.hip (depthwise convolution, NCHW) -----------------------------------------------------
+bool dwconv_supported(int K, int S);
+size_t dwconv_workspace_floats(int C, int K);
+hipError_t launch_dw_fwd(const void* x, const float* w, void* y, int N, int C, int H, int W, int OH, int OW, int K, int S,
+                         int pt, int pl, int dtype, hipStream_t st);
+hipError_t launch_dw_bwd_data(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int OH, int OW, int K,
+                              int S, int pt, int pl, int dtype, hipStream_t st);
+hipError_t launch_dw_bwd_weight(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats, int N, int C, int H,
+                                int W, int OH, int OW, int K, int S, int pt, int pl, int dtype, hipStream_t st);
+
 }  // namespace moma

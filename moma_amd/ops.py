@@ -359,3 +359,57 @@ class _BNAct(torch.autograd.Function):
 def bn_act(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float, act=None):
     """act(batch_norm(x)) on a contiguous NCHW tensor; running statistics are updated in place when training."""
     return _BNAct.apply(x, weight, bias, running_mean, running_var, bool(training), momentum, eps, ACT_CODES[act])
+
+
+# ------------------------------------------------------------------------------------------------
+# Depthwise convolution on NCHW activations (backbone helper, include/moma_hip.h "DW")
+# ------------------------------------------------------------------------------------------------
+class _DWConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad_top, pad_left, out_h, out_w):
+        lib = _lib.load()
+        _dev(x, "x", dtype=None)
+        _dev(w, "weight")
+        if x.dim() != 4 or x.dtype not in _DT_CODES or w.dim() != 4 or w.shape[1] != 1 or w.shape[0] != x.shape[1] \
+                or w.shape[2] != w.shape[3]:
+            raise ValueError(f"dwconv: x {tuple(x.shape)} {x.dtype}, weight {tuple(w.shape)}")
+        x = x.contiguous()
+        w = w.contiguous()
+        N, Cc, H, W = x.shape
+        K = w.shape[2]
+        y = torch.empty(N, Cc, out_h, out_w, device=x.device, dtype=x.dtype)
+        check(lib.moma_dwconv_fwd(_ptr(x), _ptr(w), _ptr(y), N, Cc, H, W, out_h, out_w, K, stride, pad_top, pad_left,
+                                  _DT_CODES[x.dtype], _stream()), "moma_dwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (N, Cc, H, W, out_h, out_w, K, stride, pad_top, pad_left)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        N, Cc, H, W, OH, OW, K, stride, pt, pl = ctx.cfg
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.moma_dwconv_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), N, Cc, H, W, OH, OW, K, stride, pt, pl,
+                                           _DT_CODES[x.dtype], _stream()), "moma_dwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = torch.empty(lib.moma_dwconv_workspace_bytes(Cc, K), device=x.device, dtype=torch.uint8)
+            check(lib.moma_dwconv_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel(), N, Cc, H, W, OH, OW, K,
+                                             stride, pt, pl, _DT_CODES[x.dtype], _stream()), "moma_dwconv_bwd_weight")
+        return dx, dw, None, None, None, None, None
+
+
+def dwconv_supported(kernel: int, stride: int) -> bool:
+    return kernel in (3, 5) and stride in (1, 2)
+
+
+def dwconv(x, weight, stride: int, pad_top: int, pad_left: int, out_h: int, out_w: int):
+    """Depthwise conv2d, weight [C,1,K,K] fp32, explicit (possibly asymmetric) zero padding given by the top/left pad
+    and the output size."""
+    return _DWConv.apply(x, weight, int(stride), int(pad_top), int(pad_left), int(out_h), int(out_w))

@@ -441,3 +441,35 @@ def test_bn_act_matches_torch(ops, shape, dtype, act, training):
     torch.testing.assert_close(rv2.double(), ref_rv, rtol=1e-5, atol=1e-6)
     if not training:
         assert torch.equal(rm2, rm) and torch.equal(rv2, rv)
+
+
+# ------------------------------------------------------------------------------------------------ depthwise conv
+@pytest.mark.parametrize("N,C,H,W,K,S", [(4, 8, 112, 112, 3, 1), (2, 6, 112, 112, 3, 2), (3, 5, 56, 56, 5, 2),
+                                         (2, 16, 28, 28, 5, 1), (2, 7, 14, 14, 3, 1), (3, 9, 14, 14, 5, 2),
+                                         (2, 11, 7, 7, 5, 1), (2, 3, 9, 13, 3, 2), (1, 2, 33, 17, 5, 1),
+                                         (3, 4, 30, 21, 5, 2), (64, 32, 28, 28, 5, 1), (96, 4, 57, 57, 3, 2)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv_matches_torch(ops, N, C, H, W, K, S, dtype):
+    """Depthwise conv (dwconv.hip) with TF-SAME padding (asymmetric when the total is odd) against torch conv2d in
+    fp64 on the explicitly padded input: forward, dx, dw.  Covers both kernels x strides, band splits, odd sizes,
+    strip heights R = 4 / 2 / 1 and the split reduction of the weight gradient."""
+    import math
+    g = torch.Generator(device="cpu").manual_seed(N + C + H + K + S)
+    x = torch.randn(N, C, H, W, generator=g).cuda().to(dtype)
+    w = (torch.randn(C, 1, K, K, generator=g) / K).cuda()
+    OH, OW = math.ceil(H / S), math.ceil(W / S)
+    ph, pw = max((OH - 1) * S + K - H, 0), max((OW - 1) * S + K - W, 0)
+    dy = torch.randn(N, C, OH, OW, generator=g).cuda().to(dtype)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xd, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]), wd, None, S,
+                                     0, 1, C)
+    (ref * dy.double()).sum().backward()
+    xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = ops.dwconv(xx, ww, S, ph // 2, pw // 2, OH, OW)
+    assert y.shape == ref.shape and y.dtype == dtype
+    (y.float() * dy.float()).sum().backward()
+    rtol, atol = (1e-5, 1e-5) if dtype == torch.float32 else (8e-3, 8e-3)
+    torch.testing.assert_close(y.double(), ref.detach(), rtol=rtol, atol=atol)
+    torch.testing.assert_close(xx.grad.double(), xd.grad, rtol=rtol, atol=atol)
+    torch.testing.assert_close(ww.grad.double(), wd.grad, rtol=1e-4, atol=1e-4 * (N * OH * OW) ** 0.5)
