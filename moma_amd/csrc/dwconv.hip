@@ -45,6 +45,18 @@ __device__ __forceinline__ void load_tile(float* lds, const T* __restrict__ plan
         const bool cok = col < cols && ix >= 0 && ix < W;
         const int ixc = min(max(ix, 0), W - 1);
         int r = 0;
+        // 16 loads in flight per lane (the pin below is what forces the wait; 4 per group left HBM latency exposed)
+        for (; r + 16 <= rows; r += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = ld<T>(plane + (size_t)min(max(y0 + r + u, 0), H - 1) * W + ixc);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                asm volatile("" : "+v"(v[u]));
+                const int iy = y0 + r + u;
+                if (col < cols) lds[(r + u) * pitch + col] = (cok && iy >= 0 && iy < H) ? v[u] : 0.f;
+            }
+        }
         for (; r + 4 <= rows; r += 4) {
             float v[4];
 #pragma unroll
