@@ -3,124 +3,168 @@
 // models/efficientnet_pytorch/model.py:59-64,100 `_depthwise_conv`, TF "SAME" padding from utils.py).  MIOpen has
 // no tuned gfx950 solver for them (naive_conv_*), ATen's kernels issue k*k global loads per output and are
 // address-unit bound (>50 % of the train step after the BN fusion).  The op is HBM streaming with a small stencil:
-//   * every (image, channel) plane is independent; a work item = one plane x one band of output rows, handled by ONE
-//     wave with a private LDS tile (fp32, input rows with halo, zero-filled outside the image -> asymmetric SAME
-//     padding needs no padded copy of the input), so there are no workgroup barriers and 16 waves/CU hide latency;
+//   * every (image, channel) plane is independent; a work item = PB planes x one band of output rows (large planes:
+//     PB = 1 and several bands; small planes: the whole plane and PB = 2 / 4 / 8 planes), handled by ONE wave with a
+//     private LDS tile (fp32, rows with halo) -- no workgroup barriers, 8-16 waves per CU hide the latency;
+//   * the tile is filled with 16-B / 8-B / 4-B vector loads over the planes' contiguous memory (a vector never
+//     straddles a row: VEC | W), several vectors per lane in flight, and written with one ds_write of the same
+//     width (image column 0 sits at the 16-B aligned tile column XO = 4).  Halo columns are zeroed once per wave and
+//     never written again; rows outside the image are zeroed per item -> asymmetric SAME padding needs no padded copy;
 //   * each lane owns one output column and a strip of R rows: a (R-1)*S+K tall input column per tap column is read
 //     once from LDS into registers and reused by the R outputs (10 LDS reads per output at K=5, R=4 instead of 25);
-//     consecutive lanes touch consecutive LDS words and store consecutive outputs;
-//   * the filter taps of the plane's channel are wave-uniform (scalar registers).
+//     consecutive lanes touch consecutive LDS words and store consecutive outputs; the taps of the plane's channel
+//     are wave-uniform (staged per item in LDS, read back as broadcasts).
 // backward-data, stride 1 = the same kernel on dy with the flipped filter; stride 2 = a gather in "phase" form: a
 // lane produces a 2x2 block of dx from a ceil(K/2)^2 window of dy (no divergence, no zero-insertion);
-// backward-weight = per-lane K*K fp32 accumulators over the strips of all planes a wave visits for one channel,
-// wave-reduced once at the end into partial[c][split][K*K] and summed in fixed order by a finalize kernel.
+// backward-weight = per-lane K*K fp32 accumulators over the strips of all planes a wave visits for one channel
+// (its PB planes are the same channel of consecutive images), wave-reduced once at the end into
+// partial[c][split][K*K] and summed in fixed order by a finalize kernel (deterministic).
 #include "common.hpp"
 
 namespace moma {
 namespace {
 
 constexpr int DW_WAVES = 4;                      // waves per workgroup, each with its own LDS tile
+constexpr int XO = 4;                            // tile column of image column 0 (16-B aligned, >= max left halo)
+constexpr int LDS_BUDGET = 64 * 1024;            // dynamic LDS per workgroup
 
-template <typename T> __device__ __forceinline__ float ld(const T* p);
-template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
+template <typename T, int VEC> struct Vec;
+template <> struct Vec<float, 4> { static __device__ void ld(const float* p, float* v) { const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; } };
+template <> struct Vec<float, 2> { static __device__ void ld(const float* p, float* v) { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[1] = a.y; } };
+template <> struct Vec<float, 1> { static __device__ void ld(const float* p, float* v) { v[0] = *p; } };
+template <> struct Vec<bf16_raw, 8> {
+    static __device__ void ld(const bf16_raw* p, float* v) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+};
+template <> struct Vec<bf16_raw, 4> {
+    static __device__ void ld(const bf16_raw* p, float* v) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    }
+};
+template <> struct Vec<bf16_raw, 2> {
+    static __device__ void ld(const bf16_raw* p, float* v) {
+        const unsigned a = *reinterpret_cast<const unsigned*>(p);
+        v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
+    }
+};
+template <> struct Vec<bf16_raw, 1> { static __device__ void ld(const bf16_raw* p, float* v) { v[0] = bf16_to_f32(*p); } };
+
+template <int VEC> __device__ __forceinline__ void lds_store(float* p, const float* v) {
+    if constexpr (VEC == 8) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    } else {
+        *p = v[0];
+    }
+}
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_raw>(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
 
 struct DwShape {
-    int NC, C, H, W, OH, OW, pt, pl;             // planes, channels, input / output plane size, top / left padding
-    int TH, nbands;                              // output rows per band, bands per plane
-    int IR, IWS;                                 // LDS tile rows / row pitch (floats)
+    int NC, C, H, W, OH, OW, pt, pl;             // planes, channels, source / result plane sizes, top / left padding
+    int TH, nbands, PB, ngroups;                 // band rows, bands per plane, planes per item, plane groups
+    int IR, pitch;                               // tile rows per plane, row pitch (floats, multiple of 4)
+    int GR, gpitch;                              // second tile (backward-weight: dy rows, pitch)
 };
-
-// rows [y0, y0+rows) x cols [x0, x0+cols) of one plane -> lds[r*pitch + col] (fp32), zero outside the plane.
-// Loads are unconditional from clamped addresses, pinned, then masked (a guarded load is sunk under its guard and
-// waited on one by one).
-template <typename T>
-__device__ __forceinline__ void load_tile(float* lds, const T* __restrict__ plane, int H, int W, int y0, int x0, int rows,
-                                          int cols, int pitch, int lane) {
-    for (int c0 = 0; c0 < cols; c0 += 64) {
-        const int col = c0 + lane, ix = x0 + col;
-        const bool cok = col < cols && ix >= 0 && ix < W;
-        const int ixc = min(max(ix, 0), W - 1);
-        int r = 0;
-        // 16 loads in flight per lane (the pin below is what forces the wait; 4 per group left HBM latency exposed)
-        for (; r + 16 <= rows; r += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = ld<T>(plane + (size_t)min(max(y0 + r + u, 0), H - 1) * W + ixc);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                asm volatile("" : "+v"(v[u]));
-                const int iy = y0 + r + u;
-                if (col < cols) lds[(r + u) * pitch + col] = (cok && iy >= 0 && iy < H) ? v[u] : 0.f;
-            }
-        }
-        for (; r + 4 <= rows; r += 4) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ld<T>(plane + (size_t)min(max(y0 + r + u, 0), H - 1) * W + ixc);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                asm volatile("" : "+v"(v[u]));
-                const int iy = y0 + r + u;
-                if (col < cols) lds[(r + u) * pitch + col] = (cok && iy >= 0 && iy < H) ? v[u] : 0.f;
-            }
-        }
-        for (; r < rows; ++r) {
-            float v = ld<T>(plane + (size_t)min(max(y0 + r, 0), H - 1) * W + ixc);
-            asm volatile("" : "+v"(v));
-            const int iy = y0 + r;
-            if (col < cols) lds[r * pitch + col] = (cok && iy >= 0 && iy < H) ? v : 0.f;
-        }
-    }
-}
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// ---- forward (and stride-1 backward-data with FLIP) -------------------------------------------------
-// y[p, oy, ox] = sum_{ky,kx} w[c, ky, kx] * x[p, oy*S + ky - pt, ox*S + kx - pl]
-template <typename T, int K, int S, int R, bool FLIP>
+// Fill tile rows r in [0, rows) of `np` planes: tile[(p*rows + r)*pitch + xo + col] = src_p[(y0 + r)*W + col] for image
+// rows, 0 for rows outside [0, H).  src_p = src + p*plane_stride.  Vector loads over each plane's contiguous row range.
+template <typename T, int VEC>
+__device__ __forceinline__ void fill_tile(float* tile, const T* __restrict__ src, size_t plane_stride, int np, int H, int W,
+                                          int y0, int rows, int pitch, int xo, int lane) {
+    const int ya = max(y0, 0), yb = min(y0 + rows, H);           // image rows present in the tile
+    const unsigned wv = W / VEC, nvpp = (unsigned)max(yb - ya, 0) * wv, total = nvpp * np;
+    constexpr int U = 4;                                          // vectors in flight per lane
+    for (unsigned v0 = 0; v0 < total; v0 += 64 * U) {
+        float val[U][VEC];
+        unsigned dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned v = min(v0 + u * 64 + lane, total - 1);
+            const unsigned p = v / nvpp, e = v - p * nvpp, r = e / wv, cv = e - r * wv;
+            Vec<T, VEC>::ld(src + (size_t)p * plane_stride + (size_t)(ya + r) * W + cv * VEC, val[u]);
+            dst[u] = (p * rows + (ya - y0) + r) * pitch + xo + cv * VEC;
+        }
+        // pin the loads as unconditional (else hipcc sinks each under the store's guard: load, wait, store, one by one)
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(val[u][0]));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (v0 + u * 64 + lane < total) lds_store<VEC>(tile + dst[u], val[u]);
+    }
+    // rows outside the image (wave-uniform, only at a plane's first / last band)
+    const int ztop = ya - y0, zbot = y0 + rows - max(yb, ya);
+    if (ztop > 0 || zbot > 0) {
+        for (int p = 0; p < np; ++p)
+            for (int r = 0; r < rows; ++r)
+                if (r < ztop || r >= rows - zbot)
+                    for (int c = lane; c < W; c += 64) tile[(p * rows + r) * pitch + xo + c] = 0.f;
+    }
+}
+
+template <typename T, int K, int S, int R, bool FLIP, int VEC>
 __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                              T* __restrict__ y, DwShape sh) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* tile = smem + wave * sh.IR * sh.IWS;
-    const int nitems = sh.NC * sh.nbands;
+    const int tfl = sh.PB * sh.IR * sh.pitch;                    // (multiple of 4 floats: tiles stay 16-B aligned)
+    float* tile = smem + wave * (tfl + ((sh.PB * K * K + 3) & ~3));
+    float* wl = tile + tfl;
+    for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;          // halo columns stay zero for good
+    const int nitems = sh.ngroups * sh.nbands;
     const int nstrips = (sh.TH + R - 1) / R;
-    constexpr int CR = (R - 1) * S + K;          // input rows a strip needs
+    constexpr int CR = (R - 1) * S + K;
+    const int cbase = XO - sh.pl;
     for (int item = uniform(blockIdx.x * DW_WAVES + wave); item < nitems; item += gridDim.x * DW_WAVES) {
-        const int plane = item / sh.nbands, band = item - plane * sh.nbands;
-        const int c = plane % sh.C;
-        const int oy0 = band * sh.TH;
-        const int th = min(sh.TH, sh.OH - oy0);
-        load_tile<T>(tile, x + (size_t)plane * sh.H * sh.W, sh.H, sh.W, oy0 * S - sh.pt, -sh.pl, sh.IR, sh.IWS, sh.IWS, lane);
-        float wk[K * K];                         // wave-uniform taps
-#pragma unroll
-        for (int t = 0; t < K * K; ++t) wk[t] = w[c * K * K + (FLIP ? K * K - 1 - t : t)];
+        const int grp = item / sh.nbands, band = item - grp * sh.nbands;
+        const int plane0 = grp * sh.PB, np = min(sh.PB, sh.NC - plane0);
+        const int oy0 = band * sh.TH, th = min(sh.TH, sh.OH - oy0);
+        for (int i = lane; i < np * K * K; i += 64) {
+            const int p = i / (K * K), t = i - p * (K * K);
+            wl[i] = w[((plane0 + p) % sh.C) * K * K + (FLIP ? K * K - 1 - t : t)];
+        }
+        fill_tile<T, VEC>(tile, x + (size_t)plane0 * sh.H * sh.W, (size_t)sh.H * sh.W, np, sh.H, sh.W, oy0 * S - sh.pt, sh.IR,
+                          sh.pitch, XO, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's tile stores are done (no other wave reads it)
         const int nwork = nstrips * sh.OW;
-        for (int i = lane; i < nwork; i += 64) {
-            const int strip = i / sh.OW, ox = i - strip * sh.OW;
-            float acc[R];
+        for (int p = 0; p < np; ++p) {
+            float wk[K * K];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = 0.f;
-            const float* base = tile + (strip * R * S) * sh.IWS + ox * S;
+            for (int t = 0; t < K * K; ++t) wk[t] = wl[p * K * K + t];
+            const float* pt_ = tile + p * sh.IR * sh.pitch + cbase;
+            T* yp = y + (size_t)(plane0 + p) * sh.OH * sh.OW;
+            for (int i = lane; i < nwork; i += 64) {
+                const int strip = i / sh.OW, ox = i - strip * sh.OW;
+                float acc[R];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                float col[CR];
+                for (int r = 0; r < R; ++r) acc[r] = 0.f;
+                const float* base = pt_ + (strip * R * S) * sh.pitch + ox * S;
 #pragma unroll
-                for (int rr = 0; rr < CR; ++rr) col[rr] = base[rr * sh.IWS + kx];
+                for (int kx = 0; kx < K; ++kx) {
+                    float col[CR];
+#pragma unroll
+                    for (int rr = 0; rr < CR; ++rr) col[rr] = base[rr * sh.pitch + kx];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int ky = 0; ky < K; ++ky) acc[r] = fmaf(wk[ky * K + kx], col[r * S + ky], acc[r]);
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int ky = 0; ky < K; ++ky) acc[r] = fmaf(wk[ky * K + kx], col[r * S + ky], acc[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int oy = oy0 + strip * R + r;
-                if (strip * R + r < th) st<T>(y + ((size_t)plane * sh.OH + oy) * sh.OW + ox, acc[r]);
+                    if (strip * R + r < th) st<T>(yp + (size_t)(oy0 + strip * R + r) * sh.OW + ox, acc[r]);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // tile reads done before the next item overwrites it
@@ -129,104 +173,113 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restri
 
 // ---- backward-data, stride 2 ------------------------------------------------------------------------
 // padded coordinates u = iy + pt, v = ix + pl;  dx[u = 2a+e, v = 2b+f] = sum_{t,s} w[e+2t, f+2s] * dy[a-t, b-s]
-template <typename T, int K>
+// here sh.H/W = the dy plane (source), sh.OH/OW = the dx plane (result); a band = sh.TH block rows `a`
+template <typename T, int K, int VEC>
 __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_data_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                      T* __restrict__ dx, DwShape sh) {
-    // here sh.H/W = dx plane, sh.OH/OW = dy plane; a band = sh.TH block rows `a`; tile rows = a0-HT .. a0+TH-1
     extern __shared__ float smem[];
     constexpr int HT = (K - 1) / 2;              // halo in dy rows / cols (1 for K=3, 2 for K=5)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* tile = smem + wave * sh.IR * sh.IWS;
-    const int nitems = sh.NC * sh.nbands;
-    const int nb = (sh.W + sh.pl + 2) / 2;       // block columns b = 0 .. nb-1 cover v = 0 .. W+pl
+    const int tfl = sh.PB * sh.IR * sh.pitch;
+    float* tile = smem + wave * (tfl + ((sh.PB * K * K + 3) & ~3));
+    float* wl = tile + tfl;
+    for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
+    const int nitems = sh.ngroups * sh.nbands;
+    const int nb = (sh.OW + sh.pl + 2) / 2;      // block columns b = 0 .. nb-1 cover v = 0 .. OW+pl
     for (int item = uniform(blockIdx.x * DW_WAVES + wave); item < nitems; item += gridDim.x * DW_WAVES) {
-        const int plane = item / sh.nbands, band = item - plane * sh.nbands;
-        const int c = plane % sh.C;
+        const int grp = item / sh.nbands, band = item - grp * sh.nbands;
+        const int plane0 = grp * sh.PB, np = min(sh.PB, sh.NC - plane0);
         const int a0 = band * sh.TH;
-        load_tile<T>(tile, dy + (size_t)plane * sh.OH * sh.OW, sh.OH, sh.OW, a0 - HT, -HT, sh.TH + HT, sh.IWS, sh.IWS, lane);
-        float wk[K * K];
-#pragma unroll
-        for (int t = 0; t < K * K; ++t) wk[t] = w[c * K * K + t];
+        for (int i = lane; i < np * K * K; i += 64) {
+            const int p = i / (K * K), t = i - p * (K * K);
+            wl[i] = w[((plane0 + p) % sh.C) * K * K + t];
+        }
+        fill_tile<T, VEC>(tile, dy + (size_t)plane0 * sh.H * sh.W, (size_t)sh.H * sh.W, np, sh.H, sh.W, a0 - HT, sh.IR, sh.pitch,
+                          XO, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int nwork = sh.TH * nb;
-        for (int i = lane; i < nwork; i += 64) {
-            const int ar = i / nb, b = i - ar * nb;          // block row (local), block column
-            float g[HT + 1][HT + 1];                          // g[t][s] = dy[a-t, b-s]
+        for (int p = 0; p < np; ++p) {
+            float wk[K * K];
 #pragma unroll
-            for (int t = 0; t <= HT; ++t)
+            for (int t = 0; t < K * K; ++t) wk[t] = wl[p * K * K + t];
+            const float* pt_ = tile + p * sh.IR * sh.pitch + XO;
+            T* xp = dx + (size_t)(plane0 + p) * sh.OH * sh.OW;
+            for (int i = lane; i < nwork; i += 64) {
+                const int ar = i / nb, b = i - ar * nb;       // block row (local), block column
+                float g[HT + 1][HT + 1];                       // g[t][s] = dy[a-t, b-s]; tile row of dy row a-t is ar+HT-t
 #pragma unroll
-                for (int s = 0; s <= HT; ++s) g[t][s] = tile[(ar + HT - t) * sh.IWS + (b + HT - s)];
+                for (int t = 0; t <= HT; ++t)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+                    for (int s = 0; s <= HT; ++s) g[t][s] = pt_[(ar + HT - t) * sh.pitch + (b - s)];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    float acc = 0.f;
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int t = 0; e + 2 * t < K; ++t)
+                    for (int f = 0; f < 2; ++f) {
+                        float acc = 0.f;
 #pragma unroll
-                        for (int s = 0; f + 2 * s < K; ++s) acc = fmaf(wk[(e + 2 * t) * K + f + 2 * s], g[t][s], acc);
-                    const int iy = 2 * (a0 + ar) + e - sh.pt, ix = 2 * b + f - sh.pl;
-                    if (iy >= 0 && iy < sh.H && ix >= 0 && ix < sh.W) st<T>(dx + ((size_t)plane * sh.H + iy) * sh.W + ix, acc);
-                }
+                        for (int t = 0; e + 2 * t < K; ++t)
+#pragma unroll
+                            for (int s = 0; f + 2 * s < K; ++s) acc = fmaf(wk[(e + 2 * t) * K + f + 2 * s], g[t][s], acc);
+                        const int iy = 2 * (a0 + ar) + e - sh.pt, ix = 2 * b + f - sh.pl;
+                        if (iy >= 0 && iy < sh.OH && ix >= 0 && ix < sh.OW) st<T>(xp + (size_t)iy * sh.OW + ix, acc);
+                    }
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
 }
 
 // ---- backward-weight --------------------------------------------------------------------------------
-// dw[c, ky, kx] = sum_{n, oy, ox} dy[n,c,oy,ox] * x[n,c, oy*S+ky-pt, ox*S+kx-pl];  grid (nsplit, C): one wave visits
-// planes n = first, first + stride, ... of channel c, all bands, and keeps K*K accumulators per lane.
-template <typename T, int K, int S, int R>
+// dw[c, ky, kx] = sum_{n, oy, ox} dy[n,c,oy,ox] * x[n,c, oy*S+ky-pt, ox*S+kx-pl];  grid (nsplit/4, C): one wave visits
+// image groups (PB consecutive images of channel c) x bands and keeps K*K accumulators per lane.
+template <typename T, int K, int S, int R, int VEC, int GVEC>
 __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     float* __restrict__ partial, DwShape sh, int N) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gtile = sh.TH * sh.OW;             // dy tile (floats) after the x tile
-    float* tile = smem + wave * (sh.IR * sh.IWS + gtile);
-    float* gt = tile + sh.IR * sh.IWS;
+    const int xt = sh.PB * sh.IR * sh.pitch, gtn = sh.PB * sh.GR * sh.gpitch;
+    float* tile = smem + wave * (xt + gtn);
+    float* gt = tile + xt;
+    for (int i = lane; i < xt + gtn; i += 64) tile[i] = 0.f;
     const int c = blockIdx.y;
     const int nsplit = gridDim.x * DW_WAVES, split = blockIdx.x * DW_WAVES + wave;
     const int nstrips = (sh.TH + R - 1) / R;
     constexpr int CR = (R - 1) * S + K;
+    const int cbase = XO - sh.pl;
     float acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
-    const int nitems = N * sh.nbands;
+    const size_t xs = (size_t)sh.C * sh.H * sh.W, gs = (size_t)sh.C * sh.OH * sh.OW;      // image strides
+    const int nitems = sh.ngroups * sh.nbands;
     for (int item = uniform(split); item < nitems; item += nsplit) {
-        const int n = item / sh.nbands, band = item - n * sh.nbands;
-        const size_t plane = (size_t)n * sh.C + c;
+        const int grp = item / sh.nbands, band = item - grp * sh.nbands;
+        const int n0 = grp * sh.PB, np = min(sh.PB, N - n0);
         const int oy0 = band * sh.TH;
-        const int th = min(sh.TH, sh.OH - oy0);
-        // always the full tile: rows past the image are written as zeros, so a short last band multiplies zeros (never
-        // stale LDS contents) by the zero-filled dy rows below
-        load_tile<T>(tile, x + plane * sh.H * sh.W, sh.H, sh.W, oy0 * S - sh.pt, -sh.pl, sh.IR, sh.IWS, sh.IWS, lane);
-        // dy rows of the band, zero rows past the plane's end (so that strips need no row guard)
-        {
-            const T* gp = dy + (plane * sh.OH + oy0) * sh.OW;
-            for (int i = lane; i < sh.TH * sh.OW; i += 64) {
-                const int r = i / sh.OW;
-                float v = ld<T>(gp + min(i, th * sh.OW - 1));
-                asm volatile("" : "+v"(v));
-                gt[i] = r < th ? v : 0.f;
-            }
-        }
+        fill_tile<T, VEC>(tile, x + ((size_t)n0 * sh.C + c) * sh.H * sh.W, xs, np, sh.H, sh.W, oy0 * S - sh.pt, sh.IR, sh.pitch, XO,
+                          lane);
+        // dy rows of the band; rows past the plane's end are zero, so that a short last band contributes nothing
+        fill_tile<T, GVEC>(gt, dy + ((size_t)n0 * sh.C + c) * sh.OH * sh.OW, gs, np, sh.OH, sh.OW, oy0, sh.GR, sh.gpitch, 0, lane);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int nwork = nstrips * sh.OW;
-        for (int i = lane; i < nwork; i += 64) {
-            const int strip = i / sh.OW, ox = i - strip * sh.OW;
-            float g[R];
+        for (int p = 0; p < np; ++p) {
+            const float* pt_ = tile + p * sh.IR * sh.pitch + cbase;
+            const float* gp = gt + p * sh.GR * sh.gpitch;
+            for (int i = lane; i < nwork; i += 64) {
+                const int strip = i / sh.OW, ox = i - strip * sh.OW;
+                float g[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) g[r] = (strip * R + r < sh.TH) ? gt[(strip * R + r) * sh.OW + ox] : 0.f;
-            const float* base = tile + (strip * R * S) * sh.IWS + ox * S;
+                for (int r = 0; r < R; ++r) g[r] = gp[(strip * R + r) * sh.gpitch + ox];
+                const float* base = pt_ + (strip * R * S) * sh.pitch + ox * S;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                float col[CR];
+                for (int kx = 0; kx < K; ++kx) {
+                    float col[CR];
 #pragma unroll
-                for (int rr = 0; rr < CR; ++rr) col[rr] = base[rr * sh.IWS + kx];
+                    for (int rr = 0; rr < CR; ++rr) col[rr] = base[rr * sh.pitch + kx];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                    for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int ky = 0; ky < K; ++ky) acc[ky * K + kx] = fmaf(g[r], col[r * S + ky], acc[ky * K + kx]);
+                        for (int ky = 0; ky < K; ++ky) acc[ky * K + kx] = fmaf(g[r], col[r * S + ky], acc[ky * K + kx]);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -250,79 +303,128 @@ __global__ void dw_bwd_weight_finalize_kernel(const float* __restrict__ partial,
     dw[i] = s;
 }
 
-constexpr int LDS_BUDGET = 64 * 1024;            // dynamic LDS per workgroup (4 waves)
-
-int pick_th(int OH, int rows_per_out_num, int K, int pitch, int extra_per_row, int R) {
-    // largest multiple-of-R band (<= 32 rows, <= OH rounded up to R) whose per-wave tile fits the budget
+// ---- host-side shape planning -------------------------------------------------------------------------
+int round4(int v) { return (v + 3) & ~3; }
+int pick_vec(int W, int elem_bytes, const void* a) {
+    const int maxv = 16 / elem_bytes;                           // 8 for bf16, 4 for fp32
+    for (int v = maxv; v > 1; v >>= 1)
+        if (W % v == 0 && (uintptr_t)a % (v * elem_bytes) == 0) return v;
+    return 1;
+}
+int strip_rows(int OH) { return OH >= 28 ? 4 : (OH >= 14 ? 2 : 1); }
+int planes_per_item(int OH, int OW, int nbands) {
+    if (nbands > 1) return 1;
+    const int px = OH * OW;
+    return px <= 64 ? 8 : (px <= 256 ? 4 : (px <= 1024 ? 2 : 1));
+}
+// band height: multiple of R, <= 32 rows, per-wave tiles within the LDS budget
+int pick_th(int OH, int S, int K, int pitch, int extra_floats_per_row, int R) {
     int th = ((min(OH, 32) + R - 1) / R) * R;
     while (th > R) {
-        const long floats = (long)((th - 1) * rows_per_out_num + K) * pitch + (long)th * extra_per_row;
+        const long floats = ((th - 1) * S + K) * (long)pitch + (long)th * extra_floats_per_row + K * K;
         if (floats * 4 * DW_WAVES <= LDS_BUDGET) break;
         th -= R;
     }
     return th;
 }
-
 unsigned grid_for(long nitems) {
     long g = (nitems + DW_WAVES - 1) / DW_WAVES;
     if (g > 256 * 16) g = 256 * 16;                // grid-stride beyond 16 workgroups per CU
     return (unsigned)max(1L, g);
 }
 
+// run BODY with `V` = the compile-time vector width for the run-time `vec` (8 only exists for 2-byte elements)
+#define MOMA_DW_VEC_SWITCH(vec, MAXV, BODY)                                    \
+    if (MAXV >= 8 && (vec) == 8) { constexpr int V = (MAXV >= 8 ? 8 : 4); BODY; } \
+    else if ((vec) >= 4) { constexpr int V = 4; BODY; }                        \
+    else if ((vec) == 2) { constexpr int V = 2; BODY; }                        \
+    else { constexpr int V = 1; BODY; }
+
+// y (OH x OW) from x (H x W); also backward-data stride 1 with flip = true (then x = dy and y = dx)
 template <typename T, int K, int S>
 hipError_t fwd_t(const T* x, const float* w, T* y, int NC, int C, int H, int W, int OH, int OW, int pt, int pl, bool flip,
                  hipStream_t st) {
-    DwShape sh{NC, C, H, W, OH, OW, pt, pl, 0, 0, 0, 0};
-    sh.IWS = (OW - 1) * S + K;
-    const int R = OH >= 28 ? 4 : (OH >= 14 ? 2 : 1);
-    sh.TH = pick_th(OH, S, K, sh.IWS, 0, R);
+    constexpr int MAXV = 16 / sizeof(T);
+    DwShape sh{};
+    sh.NC = NC; sh.C = C; sh.H = H; sh.W = W; sh.OH = OH; sh.OW = OW; sh.pt = pt; sh.pl = pl;
+    sh.pitch = round4(XO + max(W, (OW - 1) * S + K - pl) + 1);
+    const int R = strip_rows(OH);
+    sh.TH = pick_th(OH, S, K, sh.pitch, 0, R);
     sh.nbands = (OH + sh.TH - 1) / sh.TH;
     sh.IR = (sh.TH - 1) * S + K;
-    const size_t lds = (size_t)DW_WAVES * sh.IR * sh.IWS * sizeof(float);
-    const dim3 grid(grid_for((long)NC * sh.nbands)), block(DW_WAVES * 64);
-#define MOMA_DW_FWD(RR, FL) hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, RR, FL>), grid, block, lds, st, x, w, y, sh)
-    if (flip) { if (R == 4) MOMA_DW_FWD(4, true); else if (R == 2) MOMA_DW_FWD(2, true); else MOMA_DW_FWD(1, true); }
-    else { if (R == 4) MOMA_DW_FWD(4, false); else if (R == 2) MOMA_DW_FWD(2, false); else MOMA_DW_FWD(1, false); }
-#undef MOMA_DW_FWD
+    sh.PB = planes_per_item(OH, OW, sh.nbands);
+    while (sh.PB > 1 && (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.ngroups = (NC + sh.PB - 1) / sh.PB;
+    const size_t lds = (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * sizeof(float);
+    if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
+    const dim3 grid(grid_for((long)sh.ngroups * sh.nbands)), block(DW_WAVES * 64);
+    const int vec = pick_vec(W, sizeof(T), x);
+#define MOMA_DW_GO(RR, FL) hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, RR, FL, V>), grid, block, lds, st, x, w, y, sh)
+    MOMA_DW_VEC_SWITCH(vec, MAXV, {
+        if (flip) { if (R == 4) MOMA_DW_GO(4, true); else if (R == 2) MOMA_DW_GO(2, true); else MOMA_DW_GO(1, true); }
+        else { if (R == 4) MOMA_DW_GO(4, false); else if (R == 2) MOMA_DW_GO(2, false); else MOMA_DW_GO(1, false); }
+    })
+#undef MOMA_DW_GO
     return hipGetLastError();
 }
 
+// dx (H x W) from dy (OH x OW), stride 2
 template <typename T, int K>
 hipError_t bwd_data_s2_t(const T* dy, const float* w, T* dx, int NC, int C, int H, int W, int OH, int OW, int pt, int pl,
                          hipStream_t st) {
+    constexpr int MAXV = 16 / sizeof(T);
     constexpr int HT = (K - 1) / 2;
-    DwShape sh{NC, C, H, W, OH, OW, pt, pl, 0, 0, 0, 0};
+    DwShape sh{};
+    sh.NC = NC; sh.C = C; sh.H = OH; sh.W = OW; sh.OH = H; sh.OW = W; sh.pt = pt; sh.pl = pl;       // source = dy, result = dx
     const int nb = (W + pl + 2) / 2, na = (H + pt + 2) / 2;     // block columns / rows covering the padded plane
-    sh.IWS = nb + HT;
+    sh.pitch = round4(XO + max(OW, nb) + 1);
     int th = min(na, 16);
-    while (th > 1 && (long)(th + HT) * sh.IWS * 4 * DW_WAVES > LDS_BUDGET) --th;
+    while (th > 1 && (long)((th + HT) * sh.pitch + K * K) * 4 * DW_WAVES > LDS_BUDGET) --th;
     sh.TH = th;
     sh.nbands = (na + th - 1) / th;
     sh.IR = th + HT;
-    const size_t lds = (size_t)DW_WAVES * sh.IR * sh.IWS * sizeof(float);
-    hipLaunchKernelGGL((dw_bwd_data_s2_kernel<T, K>), dim3(grid_for((long)NC * sh.nbands)), dim3(DW_WAVES * 64), lds, st, dy, w,
-                       dx, sh);
+    sh.PB = planes_per_item(H, W, sh.nbands);
+    while (sh.PB > 1 && (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.ngroups = (NC + sh.PB - 1) / sh.PB;
+    const size_t lds = (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * sizeof(float);
+    if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
+    const dim3 grid(grid_for((long)sh.ngroups * sh.nbands)), block(DW_WAVES * 64);
+    const int vec = pick_vec(OW, sizeof(T), dy);
+    MOMA_DW_VEC_SWITCH(vec, MAXV, { hipLaunchKernelGGL((dw_bwd_data_s2_kernel<T, K, V>), grid, block, lds, st, dy, w, dx, sh); })
     return hipGetLastError();
 }
 
 template <typename T, int K, int S>
 hipError_t bwd_weight_t(const T* x, const T* dy, float* dw, float* ws, size_t ws_floats, int N, int C, int H, int W, int OH,
                         int OW, int pt, int pl, hipStream_t st) {
-    DwShape sh{N * C, C, H, W, OH, OW, pt, pl, 0, 0, 0, 0};
-    sh.IWS = (OW - 1) * S + K;
-    const int R = OH >= 28 ? 4 : (OH >= 14 ? 2 : 1);
-    sh.TH = pick_th(OH, S, K, sh.IWS, OW, R);
+    constexpr int MAXV = 16 / sizeof(T);
+    DwShape sh{};
+    sh.NC = N * C; sh.C = C; sh.H = H; sh.W = W; sh.OH = OH; sh.OW = OW; sh.pt = pt; sh.pl = pl;
+    sh.pitch = round4(XO + max(W, (OW - 1) * S + K - pl) + 1);
+    sh.gpitch = round4(OW);
+    const int R = strip_rows(OH);
+    sh.TH = pick_th(OH, S, K, sh.pitch, sh.gpitch, R);
     sh.nbands = (OH + sh.TH - 1) / sh.TH;
     sh.IR = (sh.TH - 1) * S + K;
-    const size_t lds = (size_t)DW_WAVES * (sh.IR * sh.IWS + sh.TH * sh.OW) * sizeof(float);
+    sh.GR = sh.TH;
+    sh.PB = min(planes_per_item(OH, OW, sh.nbands), N);
+    while (sh.PB > 1 && (size_t)DW_WAVES * sh.PB * (sh.IR * sh.pitch + sh.GR * sh.gpitch) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.ngroups = (N + sh.PB - 1) / sh.PB;          // groups of images (per channel)
+    const size_t lds = (size_t)DW_WAVES * sh.PB * (sh.IR * sh.pitch + sh.GR * sh.gpitch) * sizeof(float);
+    if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
     // ~8192 waves in all, at least one item per wave, partials must fit the workspace
-    long nsplit_wg = max(1L, min((long)(2048 + C - 1) / C, ((long)N * sh.nbands + DW_WAVES - 1) / DW_WAVES));
+    long nsplit_wg = max(1L, min((long)(2048 + C - 1) / C, ((long)sh.ngroups * sh.nbands + DW_WAVES - 1) / DW_WAVES));
     while (nsplit_wg > 1 && (size_t)C * nsplit_wg * DW_WAVES * K * K > ws_floats) --nsplit_wg;
     if ((size_t)C * nsplit_wg * DW_WAVES * K * K > ws_floats) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nsplit_wg, C), block(DW_WAVES * 64);
-#define MOMA_DW_BW(RR) hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S, RR>), grid, block, lds, st, x, dy, ws, sh, N)
-    if (R == 4) MOMA_DW_BW(4); else if (R == 2) MOMA_DW_BW(2); else MOMA_DW_BW(1);
-#undef MOMA_DW_BW
+    const int vec = pick_vec(W, sizeof(T), x), gvec = pick_vec(OW, sizeof(T), dy);
+    // (the dy tile takes the x tile's vector width when that divides OW too, else scalar: keeps the instantiations down)
+#define MOMA_DW_GO(RR, GV) hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S, RR, V, GV>), grid, block, lds, st, x, dy, ws, sh, N)
+    MOMA_DW_VEC_SWITCH(vec, MAXV, {
+        if (gvec >= V) { if (R == 4) MOMA_DW_GO(4, V); else if (R == 2) MOMA_DW_GO(2, V); else MOMA_DW_GO(1, V); }
+        else { if (R == 4) MOMA_DW_GO(4, 1); else if (R == 2) MOMA_DW_GO(2, 1); else MOMA_DW_GO(1, 1); }
+    })
+#undef MOMA_DW_GO
     const int total = C * K * K;
     hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, total,
                        (int)nsplit_wg * DW_WAVES, K * K);
@@ -355,7 +457,7 @@ hipError_t launch_dw_fwd(const void* x, const float* w, void* y, int N, int C, i
 hipError_t launch_dw_bwd_data(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int OH, int OW, int K,
                               int S, int pt, int pl, int dtype, hipStream_t st) {
     if (S == 1) {
-        // correlation of dy with the flipped filter, padding K-1-pt / K-1-pl; output plane = the input plane
+        // correlation of dy with the flipped filter, padding K-1-pt / K-1-pl; result plane = the input plane
         if (dtype == MOMA_DT_BF16) {
             if (K == 3) return fwd_t<bf16_raw, 3, 1>((const bf16_raw*)dy, w, (bf16_raw*)dx, N * C, C, OH, OW, H, W, 2 - pt, 2 - pl, true, st);
             if (K == 5) return fwd_t<bf16_raw, 5, 1>((const bf16_raw*)dy, w, (bf16_raw*)dx, N * C, C, OH, OW, H, W, 4 - pt, 4 - pl, true, st);
