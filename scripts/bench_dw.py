@@ -22,10 +22,12 @@ for C, H, K, S in LAYERS:
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
-    y = ops.dwconv(x, w, S, ph // 2, ph // 2, OH, OH)
     tf = t(lambda: ops.dwconv(x, w, S, ph // 2, ph // 2, OH, OH))
-    tdx = t(lambda: torch.autograd.grad(y, x, dy, retain_graph=True))
-    tdw = t(lambda: torch.autograd.grad(y, w, dy, retain_graph=True))
+    # needs_input_grad follows requires_grad of the inputs, so build one graph per gradient
+    y1 = ops.dwconv(x, w.detach(), S, ph // 2, ph // 2, OH, OH)
+    tdx = t(lambda: torch.autograd.grad(y1, x, dy, retain_graph=True))
+    y2 = ops.dwconv(x.detach(), w, S, ph // 2, ph // 2, OH, OH)
+    tdw = t(lambda: torch.autograd.grad(y2, w, dy, retain_graph=True))
     bx, by = x.numel() * 2, dy.numel() * 2
     print(f"C={C:5d} {H:3d}x{H:<3d} k{K} s{S}: fwd {tf:7.1f} us {((bx+by)/tf/1e3):6.0f} GB/s | bwd-data {tdx:7.1f} us "
           f"{((bx+by)/tdx/1e3):6.0f} GB/s | bwd-weight {tdw:7.1f} us {((bx+by)/tdw/1e3):6.0f} GB/s", flush=True)
