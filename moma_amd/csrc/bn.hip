@@ -148,35 +148,54 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
     }
 }
 
-// one thread per channel: merge the S partials, write save_mean / save_invstd / scale / shift, update running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int S, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd, float* __restrict__ scale_shift, int C,
-                                   int training, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel (4 channels per workgroup): lane s holds partial s, the S <= 64 partials are merged with a
+// butterfly of Chan updates (fixed order -> deterministic); writes save_mean / save_invstd / scale / shift and
+// updates the running statistics
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int S,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          float* __restrict__ scale_shift, int C, int training,
+                                                          float momentum, float eps) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float mean, invstd;
     if (training) {
         float n = 0.f, m2 = 0.f;
         mean = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float* p = partial + ((size_t)c * S + s) * 3;
-            merge(n, mean, m2, p[0], p[1], p[2]);
+        if (lane < S) {
+            const float* p = partial + ((size_t)c * S + lane) * 3;
+            n = p[0]; mean = p[1]; m2 = p[2];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+            // both partners must end with the same triple: merge in a fixed (lower lane first) order
+            if (lane & o) {
+                float n2 = nb, mean2 = mb, m22 = qb;
+                merge(n2, mean2, m22, n, mean, m2);
+                n = n2; mean = mean2; m2 = m22;
+            } else {
+                merge(n, mean, m2, nb, mb, qb);
+            }
         }
         const float var = m2 / n;                               // biased, used for normalisation
         invstd = rsqrtf(var + eps);
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+        if (lane == 0) {
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+        }
     } else {
         mean = running_mean[c];
         invstd = rsqrtf(running_var[c] + eps);
     }
-    if (save_mean) save_mean[c] = mean;
-    if (save_invstd) save_invstd[c] = invstd;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    scale_shift[2 * c] = g * invstd;
-    scale_shift[2 * c + 1] = b - mean * g * invstd;
+    if (lane == 0) {
+        if (save_mean) save_mean[c] = mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        scale_shift[2 * c] = g * invstd;
+        scale_shift[2 * c + 1] = b - mean * g * invstd;
+    }
 }
 
 // out = act(x * scale[c] + shift[c])
@@ -237,18 +256,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-// per channel: dgamma, dbeta and the coefficients of dx = a*dy - a*b1 - a*b2*xhat  (training);  eval: dx = a*dy
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int S, const float* __restrict__ gamma,
-                                       const float* __restrict__ save_invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef, int C, float count,
-                                       int training) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// per channel (one wave each): dgamma, dbeta and the coefficients of dx = a*dy - a*b1 - a*b2*xhat (training); eval: dx = a*dy
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int S,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ save_invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef, int C,
+                                                              float count, int training) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < S; ++s) {
-        s1 += partial[((size_t)c * S + s) * 2];
-        s2 += partial[((size_t)c * S + s) * 2 + 1];
+    if (lane < S) {
+        s1 = partial[((size_t)c * S + lane) * 2];
+        s2 = partial[((size_t)c * S + lane) * 2 + 1];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane != 0) return;
     if (dgamma) dgamma[c] = s2;
     if (dbeta) dbeta[c] = s1;
     const float a = (gamma ? gamma[c] : 1.f) * save_invstd[c];
@@ -321,7 +344,7 @@ hipError_t bn_fwd_t(const T* x, T* out, const float* gamma, const float* beta, f
         else if (vec == 4) hipLaunchKernelGGL((bn_stats_kernel<T, 4>), grid, dim3(BN_THREADS), 0, st, x, partial, N, C, HW);
         else hipLaunchKernelGGL((bn_stats_kernel<T, 1>), grid, dim3(BN_THREADS), 0, st, x, partial, N, C, HW);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, partial, S, gamma, beta, rm, rv,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, S, gamma, beta, rm, rv,
                        save_mean, save_invstd, scale_shift, C, training, momentum, eps);
     const unsigned g = apply_grid(nvec);
     if (vec == 8) hipLaunchKernelGGL((bn_apply_kernel<T, 8>), dim3(g), dim3(BN_THREADS), 0, st, x, out, scale_shift, C, HW, nvec, act);
@@ -343,7 +366,7 @@ hipError_t bn_bwd_t(const T* x, const T* dout, const float* gamma, const float* 
     if (vec == 8) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
     else if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, partial, S, gamma, save_invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, S, gamma, save_invstd,
                        dgamma, dbeta, coef, C, (float)N * (float)HW, training);
     if (dx) {
         const unsigned g = apply_grid(nvec);
