@@ -54,7 +54,14 @@ constexpr int QROWS_WG = 128;        // query rows per workgroup (4 waves x 32)
 constexpr int KT = 32;               // keys per tile
 constexpr int NBUF = 4;              // LDS ring: tile t is consumed while t+1..t+3 are in flight (LDS-DMA)
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float OVERFLOW_THR = 64.0f; // log2 units: P <= 2^64 relative to the fixed reference max
+// The fixed softmax reference of a wave is (row max of its chunk's first tile) + REF_MARGIN.  Only P's exponent moves
+// with the reference (bf16 / fp32 share the 8-bit exponent, down to 2^-126), so starting 2^-32 low costs nothing
+// and leaves REF_MARGIN + OVERFLOW_THR = 128 log2 units (61 nats of logit) of headroom above the first tile's max before
+// the repair launch is needed; sums stay below 2^(96 + 9) per chunk.  (Un-normalised attention outputs as q / keys do
+// reach logit ranges of tens of nats in training: with the margin at 0 and the threshold at 64 the repair pass --
+// 4x the cost of the main pass -- fired every other step of the benchmark from step 20 on.)
+constexpr float REF_MARGIN = 32.0f;
+constexpr float OVERFLOW_THR = 96.0f;
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
 // REPAIR = false: first (normally only) launch.  The softmax reference m of a wave is FIXED to the row max of
 //   its chunk's first tile: bf16 and fp32 share the 8-bit exponent, so P = 2^(x - m) may exceed 1 by many
 //   orders of magnitude without losing precision and O is never rescaled.  A wave that meets a score more than
-//   2^OVERFLOW_THR above m raises flag[chunk][wave-of-rows]; its partials are then invalid.
+//   2^OVERFLOW_THR above m raises flag[chunk][wave-of-rows]; its partials are then invalid.  (m = first-tile max + REF_MARGIN)
 // REPAIR = true : second launch of the same grid; workgroups without a raised flag exit at once, flagged
 //   waves redo their chunk with m = the true chunk max the first launch recorded (x_part) -- cannot overflow.
 template <int D, bool WITH_DQ, bool REPAIR>
@@ -328,7 +335,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
         if constexpr (!REPAIR) {
-            if (first) m_ref = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (first) m_ref = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) + REF_MARGIN;
         }
         tile_stats(tmax);
         float psum = 0.f;

@@ -196,17 +196,20 @@ def test_infonce_flash_queue_term(ops, B, d, K):
     assert err.max() < 2e-2, err.max()
 
 
-def test_infonce_flash_overflow_repair(ops):
-    """A key far down the chunk beats the first tile's max by > 2^64: the first launch flags the wave and the
-    repair launch redoes the chunk with the true chunk max (rule 26: force the rare branch, full reference)."""
+@pytest.mark.parametrize("scale", [30.0, 25.0, 10.0, 6.0])
+def test_infonce_flash_overflow_repair(ops, scale):
+    """A key far down the chunk beats the first tile's max by tens to hundreds of log2 units.  Beyond the fixed
+    reference's headroom (128) the first launch flags the wave and the repair launch redoes the chunk with the true
+    chunk max (rule 26: force the rare branch, full reference: scale 30 / 25 -> ~290 / 240 log2 units); below it
+    (scale 10 / 6 -> ~96 / 58) the single pass must carry the range by itself."""
     rng = np.random.default_rng(7)
     B, d, K, T = 40, 256, 3000, 0.15
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
     # rows 5 and 17 see a huge logit at keys 1500 / 2999 (late tiles of their chunks): s = |q|*30/T ~ 200 nats
-    queue[1500] = 30.0 * q[5] / np.linalg.norm(q[5])
-    queue[2999] = 25.0 * q[17] / np.linalg.norm(q[17])
+    queue[1500] = scale * q[5] / np.linalg.norm(q[5])
+    queue[2999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
     tq = _t(q).requires_grad_(True)
     tqueue = _t(queue, torch.bfloat16)
     qe = tqueue.float().cpu().numpy()
