@@ -80,21 +80,31 @@ struct DwShape {
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// i / d for 0 <= i < 2^20 (a work index inside one tile), d >= 1: the float quotient is within one of the answer
+// (3 instructions + the fix-up instead of the ~25 of an integer division by a run-time value)
+__device__ __forceinline__ int fast_div(int i, int d, float inv_d) {
+    int q = (int)((float)i * inv_d);
+    q += (q + 1) * d <= i;
+    q -= q * d > i;
+    return q;
+}
+
 // Fill tile rows r in [0, rows) of `np` planes: tile[(p*rows + r)*pitch + xo + col] = src_p[(y0 + r)*W + col] for image
 // rows, 0 for rows outside [0, H).  src_p = src + p*plane_stride.  Vector loads over each plane's contiguous row range.
 template <typename T, int VEC>
 __device__ __forceinline__ void fill_tile(float* tile, const T* __restrict__ src, size_t plane_stride, int np, int H, int W,
-                                          int y0, int rows, int pitch, int xo, int lane) {
+                                          int y0, int rows, int pitch, int xo, int lane, bool zero_rows) {
     const int ya = max(y0, 0), yb = min(y0 + rows, H);           // image rows present in the tile
-    const unsigned wv = W / VEC, nvpp = (unsigned)max(yb - ya, 0) * wv, total = nvpp * np;
+    const int wv = W / VEC, nvpp = max(yb - ya, 0) * wv, total = nvpp * np;
+    const float inv_nvpp = 1.0f / (float)max(nvpp, 1), inv_wv = 1.0f / (float)wv;
     constexpr int U = 4;                                          // vectors in flight per lane
-    for (unsigned v0 = 0; v0 < total; v0 += 64 * U) {
+    for (int v0 = 0; v0 < total; v0 += 64 * U) {
         float val[U][VEC];
-        unsigned dst[U];
+        int dst[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned v = min(v0 + u * 64 + lane, total - 1);
-            const unsigned p = v / nvpp, e = v - p * nvpp, r = e / wv, cv = e - r * wv;
+            const int v = min(v0 + u * 64 + lane, total - 1);
+            const int p = fast_div(v, nvpp, inv_nvpp), e = v - p * nvpp, r = fast_div(e, wv, inv_wv), cv = e - r * wv;
             Vec<T, VEC>::ld(src + (size_t)p * plane_stride + (size_t)(ya + r) * W + cv * VEC, val[u]);
             dst[u] = (p * rows + (ya - y0) + r) * pitch + xo + cv * VEC;
         }
@@ -105,9 +115,10 @@ __device__ __forceinline__ void fill_tile(float* tile, const T* __restrict__ src
         for (int u = 0; u < U; ++u)
             if (v0 + u * 64 + lane < total) lds_store<VEC>(tile + dst[u], val[u]);
     }
-    // rows outside the image (wave-uniform, only at a plane's first / last band)
+    // rows outside the image (wave-uniform, only at a plane's first / last band).  With one band per plane the row
+    // mapping never changes and those rows keep the zeros of the initial clear: zero_rows = false.
     const int ztop = ya - y0, zbot = y0 + rows - max(yb, ya);
-    if (ztop > 0 || zbot > 0) {
+    if (zero_rows && (ztop > 0 || zbot > 0)) {
         for (int p = 0; p < np; ++p)
             for (int r = 0; r < rows; ++r)
                 if (r < ztop || r >= rows - zbot)
@@ -137,9 +148,10 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restri
             wl[i] = w[((plane0 + p) % sh.C) * K * K + (FLIP ? K * K - 1 - t : t)];
         }
         fill_tile<T, VEC>(tile, x + (size_t)plane0 * sh.H * sh.W, (size_t)sh.H * sh.W, np, sh.H, sh.W, oy0 * S - sh.pt, sh.IR,
-                          sh.pitch, XO, lane);
+                          sh.pitch, XO, lane, sh.nbands > 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's tile stores are done (no other wave reads it)
         const int nwork = nstrips * sh.OW;
+        const float inv_ow = 1.0f / (float)sh.OW;
         for (int p = 0; p < np; ++p) {
             float wk[K * K];
 #pragma unroll
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restri
             const float* pt_ = tile + p * sh.IR * sh.pitch + cbase;
             T* yp = y + (size_t)(plane0 + p) * sh.OH * sh.OW;
             for (int i = lane; i < nwork; i += 64) {
-                const int strip = i / sh.OW, ox = i - strip * sh.OW;
+                const int strip = fast_div(i, sh.OW, inv_ow), ox = i - strip * sh.OW;
                 float acc[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -162,9 +174,15 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restri
 #pragma unroll
                         for (int ky = 0; ky < K; ++ky) acc[r] = fmaf(wk[ky * K + kx], col[r * S + ky], acc[r]);
                 }
+                T* o = yp + (size_t)(oy0 + strip * R) * sh.OW + ox;
+                if (strip * R + R <= th) {       // whole strip inside the band: no per-row guards
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (strip * R + r < th) st<T>(yp + (size_t)(oy0 + strip * R + r) * sh.OW + ox, acc[r]);
+                    for (int r = 0; r < R; ++r) st<T>(o + r * sh.OW, acc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (strip * R + r < th) st<T>(o + r * sh.OW, acc[r]);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // tile reads done before the next item overwrites it
@@ -195,9 +213,10 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_data_s2_kernel(const T* 
             wl[i] = w[((plane0 + p) % sh.C) * K * K + t];
         }
         fill_tile<T, VEC>(tile, dy + (size_t)plane0 * sh.H * sh.W, (size_t)sh.H * sh.W, np, sh.H, sh.W, a0 - HT, sh.IR, sh.pitch,
-                          XO, lane);
+                          XO, lane, sh.nbands > 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int nwork = sh.TH * nb;
+        const float inv_nb = 1.0f / (float)nb;
         for (int p = 0; p < np; ++p) {
             float wk[K * K];
 #pragma unroll
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_data_s2_kernel(const T* 
             const float* pt_ = tile + p * sh.IR * sh.pitch + XO;
             T* xp = dx + (size_t)(plane0 + p) * sh.OH * sh.OW;
             for (int i = lane; i < nwork; i += 64) {
-                const int ar = i / nb, b = i - ar * nb;       // block row (local), block column
+                const int ar = fast_div(i, nb, inv_nb), b = i - ar * nb;       // block row (local), block column
                 float g[HT + 1][HT + 1];                       // g[t][s] = dy[a-t, b-s]; tile row of dy row a-t is ar+HT-t
 #pragma unroll
                 for (int t = 0; t <= HT; ++t)
@@ -256,16 +275,18 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_weight_kernel(const T* _
         const int n0 = grp * sh.PB, np = min(sh.PB, N - n0);
         const int oy0 = band * sh.TH;
         fill_tile<T, VEC>(tile, x + ((size_t)n0 * sh.C + c) * sh.H * sh.W, xs, np, sh.H, sh.W, oy0 * S - sh.pt, sh.IR, sh.pitch, XO,
-                          lane);
+                          lane, sh.nbands > 1);
         // dy rows of the band; rows past the plane's end are zero, so that a short last band contributes nothing
-        fill_tile<T, GVEC>(gt, dy + ((size_t)n0 * sh.C + c) * sh.OH * sh.OW, gs, np, sh.OH, sh.OW, oy0, sh.GR, sh.gpitch, 0, lane);
+        fill_tile<T, GVEC>(gt, dy + ((size_t)n0 * sh.C + c) * sh.OH * sh.OW, gs, np, sh.OH, sh.OW, oy0, sh.GR, sh.gpitch, 0, lane,
+                           sh.nbands > 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int nwork = nstrips * sh.OW;
+        const float inv_ow = 1.0f / (float)sh.OW;
         for (int p = 0; p < np; ++p) {
             const float* pt_ = tile + p * sh.IR * sh.pitch + cbase;
             const float* gp = gt + p * sh.GR * sh.gpitch;
             for (int i = lane; i < nwork; i += 64) {
-                const int strip = i / sh.OW, ox = i - strip * sh.OW;
+                const int strip = fast_div(i, sh.OW, inv_ow), ox = i - strip * sh.OW;
                 float g[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) g[r] = gp[(strip * R + r) * sh.gpitch + ox];
@@ -317,15 +338,19 @@ int planes_per_item(int OH, int OW, int nbands) {
     const int px = OH * OW;
     return px <= 64 ? 8 : (px <= 256 ? 4 : (px <= 1024 ? 2 : 1));
 }
-// band height: multiple of R, <= 32 rows, per-wave tiles within the LDS budget
+// band height: the largest multiple of R (<= OH rounded up) whose per-wave tile stays within WAVE_TILE_FLOATS --
+// occupancy matters more than halo re-reads: ~10 KiB per wave keeps 16 waves per CU resident (measured on the
+// 112 x 112 layers: 28-row bands / 8 waves per CU 1.86 TB/s, 16-row bands / 16 waves 3.1 TB/s)
+constexpr int WAVE_TILE_FLOATS = 2560;
 int pick_th(int OH, int S, int K, int pitch, int extra_floats_per_row, int R) {
-    int th = ((min(OH, 32) + R - 1) / R) * R;
-    while (th > R) {
-        const long floats = ((th - 1) * S + K) * (long)pitch + (long)th * extra_floats_per_row + K * K;
-        if (floats * 4 * DW_WAVES <= LDS_BUDGET) break;
-        th -= R;
-    }
-    return th;
+    int th = ((OH + R - 1) / R) * R;
+    while (th > R && ((th - 1) * S + K) * (long)pitch + (long)th * extra_floats_per_row > WAVE_TILE_FLOATS) th -= R;
+    const int nbands = (OH + th - 1) / th;       // equal bands instead of full ones plus a remainder
+    return (((OH + nbands - 1) / nbands + R - 1) / R) * R;
+}
+int fit_planes(int pb, long floats_per_plane) {
+    while (pb > 1 && pb * floats_per_plane > WAVE_TILE_FLOATS) pb >>= 1;
+    return pb;
 }
 unsigned grid_for(long nitems) {
     long g = (nitems + DW_WAVES - 1) / DW_WAVES;
@@ -352,8 +377,7 @@ hipError_t fwd_t(const T* x, const float* w, T* y, int NC, int C, int H, int W, 
     sh.TH = pick_th(OH, S, K, sh.pitch, 0, R);
     sh.nbands = (OH + sh.TH - 1) / sh.TH;
     sh.IR = (sh.TH - 1) * S + K;
-    sh.PB = planes_per_item(OH, OW, sh.nbands);
-    while (sh.PB > 1 && (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.PB = fit_planes(planes_per_item(OH, OW, sh.nbands), (long)sh.IR * sh.pitch);
     sh.ngroups = (NC + sh.PB - 1) / sh.PB;
     const size_t lds = (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * sizeof(float);
     if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
@@ -378,13 +402,13 @@ hipError_t bwd_data_s2_t(const T* dy, const float* w, T* dx, int NC, int C, int 
     sh.NC = NC; sh.C = C; sh.H = OH; sh.W = OW; sh.OH = H; sh.OW = W; sh.pt = pt; sh.pl = pl;       // source = dy, result = dx
     const int nb = (W + pl + 2) / 2, na = (H + pt + 2) / 2;     // block columns / rows covering the padded plane
     sh.pitch = round4(XO + max(OW, nb) + 1);
-    int th = min(na, 16);
-    while (th > 1 && (long)((th + HT) * sh.pitch + K * K) * 4 * DW_WAVES > LDS_BUDGET) --th;
+    int th = na;
+    while (th > 1 && (long)(th + HT) * sh.pitch > WAVE_TILE_FLOATS) --th;
+    th = (na + (na + th - 1) / th - 1) / ((na + th - 1) / th);       // equal bands
     sh.TH = th;
     sh.nbands = (na + th - 1) / th;
     sh.IR = th + HT;
-    sh.PB = planes_per_item(H, W, sh.nbands);
-    while (sh.PB > 1 && (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.PB = fit_planes(planes_per_item(H, W, sh.nbands), (long)sh.IR * sh.pitch);
     sh.ngroups = (NC + sh.PB - 1) / sh.PB;
     const size_t lds = (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * sizeof(float);
     if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
@@ -407,8 +431,7 @@ hipError_t bwd_weight_t(const T* x, const T* dy, float* dw, float* ws, size_t ws
     sh.nbands = (OH + sh.TH - 1) / sh.TH;
     sh.IR = (sh.TH - 1) * S + K;
     sh.GR = sh.TH;
-    sh.PB = min(planes_per_item(OH, OW, sh.nbands), N);
-    while (sh.PB > 1 && (size_t)DW_WAVES * sh.PB * (sh.IR * sh.pitch + sh.GR * sh.gpitch) * 4 > (size_t)LDS_BUDGET) sh.PB >>= 1;
+    sh.PB = fit_planes(min(planes_per_item(OH, OW, sh.nbands), N), (long)sh.IR * sh.pitch + (long)sh.GR * sh.gpitch);
     sh.ngroups = (N + sh.PB - 1) / sh.PB;          // groups of images (per channel)
     const size_t lds = (size_t)DW_WAVES * sh.PB * (sh.IR * sh.pitch + sh.GR * sh.gpitch) * sizeof(float);
     if (lds > (size_t)LDS_BUDGET) return hipErrorInvalidValue;
