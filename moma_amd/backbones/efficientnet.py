@@ -99,12 +99,28 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d (same parameters / buffers / state-dict keys) with an optional fused activation.
     On the GPU the pair runs on the library's kernels (`ops.bn_act`); elsewhere it is BN followed by the activation."""
 
+    _nbt_pending = 0       # forward calls not yet added to the `num_batches_tracked` buffer (a 1-element GPU add per
+                           # BN call otherwise: 144 launches per step); flushed whenever the buffer is read out
+
+    def _flush_nbt(self):
+        if self._nbt_pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(self._nbt_pending)
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_nbt()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, x, act=None):
-        if _BN_MODE == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        if _BN_MODE == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.momentum is not None:
             from .. import ops
             use_batch = self.training or self.running_mean is None
             if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+                self._nbt_pending += 1
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, use_batch,
                               self.momentum, self.eps, act)
         if _BN_MODE == "aten" and x.is_cuda:

@@ -476,3 +476,27 @@ def test_dwconv_matches_torch(ops, N, C, H, W, K, S, dtype):
     torch.testing.assert_close(y.double(), ref.detach(), rtol=rtol, atol=atol)
     torch.testing.assert_close(xx.grad.double(), xd.grad, rtol=rtol, atol=atol)
     torch.testing.assert_close(ww.grad.double(), wd.grad, rtol=1e-4, atol=1e-4 * (N * OH * OW) ** 0.5)
+
+
+def test_backbone_bn_module_state(ops):
+    """The backbone's BatchNorm2d (fused kernels) keeps nn.BatchNorm2d's state: running statistics after a few
+    training calls, the lazily flushed `num_batches_tracked`, eval-mode output and state-dict keys."""
+    from moma_amd.backbones.efficientnet import BatchNorm2d
+    torch.manual_seed(3)
+    mine = BatchNorm2d(24, momentum=0.01, eps=1e-3).cuda()
+    ref = torch.nn.BatchNorm2d(24, momentum=0.01, eps=1e-3).cuda()
+    with torch.no_grad():
+        mine.weight.uniform_(0.5, 1.5); mine.bias.uniform_(-0.3, 0.3)
+        ref.load_state_dict(mine.state_dict())
+    for i in range(3):
+        x = torch.randn(16, 24, 28, 28, device="cuda") * (1 + i) + i
+        y, yr = mine(x, act="silu"), torch.nn.functional.silu(ref(x))
+        torch.testing.assert_close(y, yr, rtol=2e-5, atol=2e-5)
+    sd, sdr = mine.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(sdr.keys())
+    assert int(sd["num_batches_tracked"]) == 3
+    torch.testing.assert_close(sd["running_mean"], sdr["running_mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sd["running_var"], sdr["running_var"], rtol=1e-5, atol=1e-6)
+    mine.eval(); ref.eval()
+    x = torch.randn(4, 24, 28, 28, device="cuda")
+    torch.testing.assert_close(mine(x), ref(x), rtol=2e-5, atol=2e-5)
