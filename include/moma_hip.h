@@ -177,6 +177,19 @@ int moma_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* works
                            size_t workspace_bytes, int N, int C, int H, int W, int OH, int OW, int K,
                            int stride, int pad_top, int pad_left, int dtype, moma_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SE  squeeze-excite helpers on NCHW activations (models/efficientnet_pytorch/model.py:104-110):
+ *     moma_plane_mean     mean[n,c] = mean_hw x[n,c,:,:]                       (F.adaptive_avg_pool2d(x, 1))
+ *     moma_se_gate_fwd    out = x * sigmoid(s[n,c])                            (torch.sigmoid(x_squeezed) * x)
+ *     moma_se_gate_bwd    dx = dout * sigmoid(s);  ds = sigmoid'(s) * sum_hw(dout * x)   -- one pass
+ *     x, out, dout, dx: [NC, HW] contiguous; mean, s, ds: [NC]; all of dtype MOMA_DT_F32 or MOMA_DT_BF16.
+ *     Throughput helpers of the step like BN / DW, not KD-term kernels.
+ * ------------------------------------------------------------------------------------------- */
+int moma_plane_mean(const void* x, void* mean, int NC, int HW, int dtype, moma_stream_t stream);
+int moma_se_gate_fwd(const void* x, const void* s, void* out, int NC, int HW, int dtype, moma_stream_t stream);
+int moma_se_gate_bwd(const void* x, const void* s, const void* dout, void* dx, void* ds, int NC, int HW,
+                     int dtype, moma_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ SIGNATURES = {
     "moma_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
     "moma_dwconv_bwd_data": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
     "moma_dwconv_bwd_weight": (_i, [_p, _p, _p, _p, _z] + [_i] * 11 + [_p]),
+    "moma_plane_mean": (_i, [_p, _p, _i, _i, _i, _p]),
+    "moma_se_gate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "moma_se_gate_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "moma_bn_workspace_bytes": (_z, [_i]),
     "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),

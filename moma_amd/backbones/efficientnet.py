@@ -24,6 +24,9 @@ import torch.nn.functional as F
 #                           ~10 % of HBM peak on these shapes); "aten" = ATen's native BN (5 % slower than MIOpen).
 _DW_MODE = os.environ.get("MOMA_DW", "hip")
 _BN_MODE = os.environ.get("MOMA_BN", "hip")
+#   squeeze-excite        : MOMA_SE=hip (default) = per-plane mean and the sigmoid gate (one-pass backward) on the
+#                           library's kernels (se.hip); "aten" = adaptive_avg_pool2d / sigmoid / mul.
+_SE_MODE = os.environ.get("MOMA_SE", "hip")
 
 # (repeats, kernel, stride, expand, cin, cout, se_ratio) -- EfficientNet-B0 stage table
 _B0_STAGES = [
@@ -160,9 +163,14 @@ class MBConvBlock(nn.Module):
         if self.expand != 1:
             x = self._bn0(self._expand_conv(x), act="silu")
         x = self._bn1(self._depthwise_conv(x), act="silu")
-        s = F.adaptive_avg_pool2d(x, 1)
-        s = self._se_expand(F.silu(self._se_reduce(s)))
-        x = torch.sigmoid(s) * x
+        if _SE_MODE == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            from .. import ops
+            s = self._se_expand(F.silu(self._se_reduce(ops.plane_mean(x))))
+            x = ops.se_gate(x, s)
+        else:
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = self._se_expand(F.silu(self._se_reduce(s)))
+            x = torch.sigmoid(s) * x
         x = self._bn2(self._project_conv(x))
         if self.stride == 1 and self.cin == self.cout:
             x = _drop_connect(x, drop_connect_rate, self.training) + inp

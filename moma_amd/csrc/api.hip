@@ -326,4 +326,26 @@ int moma_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* works
                                        stride, pad_top, pad_left, dtype, (hipStream_t)stream));
 }
 
+static int se_check(int NC, int HW, int dtype) {
+    if (NC <= 0 || HW <= 0) return MOMA_E_SHAPE;
+    if (dtype != MOMA_DT_F32 && dtype != MOMA_DT_BF16) return MOMA_E_DTYPE;
+    return MOMA_OK;
+}
+int moma_plane_mean(const void* x, void* mean, int NC, int HW, int dtype, moma_stream_t stream) {
+    if (!x || !mean) return MOMA_E_NULL;
+    const int rc = se_check(NC, HW, dtype);
+    return rc != MOMA_OK ? rc : hip_rc(launch_plane_mean(x, mean, NC, HW, dtype, (hipStream_t)stream));
+}
+int moma_se_gate_fwd(const void* x, const void* s, void* out, int NC, int HW, int dtype, moma_stream_t stream) {
+    if (!x || !s || !out) return MOMA_E_NULL;
+    const int rc = se_check(NC, HW, dtype);
+    return rc != MOMA_OK ? rc : hip_rc(launch_se_gate_fwd(x, s, out, NC, HW, dtype, (hipStream_t)stream));
+}
+int moma_se_gate_bwd(const void* x, const void* s, const void* dout, void* dx, void* ds, int NC, int HW, int dtype,
+                     moma_stream_t stream) {
+    if (!x || !s || !dout || !dx || !ds) return MOMA_E_NULL;
+    const int rc = se_check(NC, HW, dtype);
+    return rc != MOMA_OK ? rc : hip_rc(launch_se_gate_bwd(x, s, dout, dx, ds, NC, HW, dtype, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -101,4 +101,10 @@ hipError_t launch_dw_bwd_data(const void* dy, const float* w, void* dx, int N, i
 hipError_t launch_dw_bwd_weight(const void* x, const void* dy, float* dw, float* ws, size_t ws_floats, int N, int C, int H,
                                 int W, int OH, int OW, int K, int S, int pt, int pl, int dtype, hipStream_t st);
 
+// ---- se.hip (squeeze-excite: per-plane mean, sigmoid gate) ----------------------------------------------
+hipError_t launch_plane_mean(const void* x, void* out, int NC, int HW, int dtype, hipStream_t st);
+hipError_t launch_se_gate_fwd(const void* x, const void* s, void* out, int NC, int HW, int dtype, hipStream_t st);
+hipError_t launch_se_gate_bwd(const void* x, const void* s, const void* dout, void* dx, void* ds, int NC, int HW, int dtype,
+                              hipStream_t st);
+
 }  // namespace moma

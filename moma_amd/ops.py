@@ -33,13 +33,13 @@ def _qdtype(queue: torch.Tensor) -> int:
     raise TypeError(f"queue dtype must be float32 or bfloat16, got {queue.dtype}")
 
 
-def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32, contiguous=True) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise MomaHipError(f"{name}: the MoMA hot path runs only on the GPU (HIP library); got a "
                            f"{'CPU tensor' if isinstance(t, torch.Tensor) else type(t)}. No CPU fallback exists.")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_contiguous():
+    if contiguous and not t.is_contiguous():
         raise ValueError(f"{name}: must be contiguous")
     return t
 
@@ -319,7 +319,7 @@ class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
         lib = _lib.load()
-        _dev(x, "x", dtype=None)
+        _dev(x, "x", dtype=None, contiguous=False)
         if x.dim() < 2 or x.dtype not in _DT_CODES:
             raise ValueError(f"bn_act: expects [N, C, ...] float32 / bfloat16, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()
@@ -368,7 +368,7 @@ class _DWConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad_top, pad_left, out_h, out_w):
         lib = _lib.load()
-        _dev(x, "x", dtype=None)
+        _dev(x, "x", dtype=None, contiguous=False)
         _dev(w, "weight")
         if x.dim() != 4 or x.dtype not in _DT_CODES or w.dim() != 4 or w.shape[1] != 1 or w.shape[0] != x.shape[1] \
                 or w.shape[2] != w.shape[3]:
@@ -413,3 +413,67 @@ def dwconv(x, weight, stride: int, pad_top: int, pad_left: int, out_h: int, out_
     """Depthwise conv2d, weight [C,1,K,K] fp32, explicit (possibly asymmetric) zero padding given by the top/left pad
     and the output size."""
     return _DWConv.apply(x, weight, int(stride), int(pad_top), int(pad_left), int(out_h), int(out_w))
+
+
+# ------------------------------------------------------------------------------------------------
+# Squeeze-excite helpers (include/moma_hip.h "SE")
+# ------------------------------------------------------------------------------------------------
+class _PlaneMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _dev(x, "x", dtype=None, contiguous=False)
+        if x.dim() != 4 or x.dtype not in _DT_CODES:
+            raise ValueError(f"plane_mean: expects [N,C,H,W] float32 / bfloat16, got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        out = torch.empty(N, Cc, 1, 1, device=x.device, dtype=x.dtype)
+        check(lib.moma_plane_mean(_ptr(x), _ptr(out), N * Cc, H * W, _DT_CODES[x.dtype], _stream()), "moma_plane_mean")
+        ctx.shape = (N, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dmean):
+        N, Cc, H, W = ctx.shape
+        return (dmean / (H * W)).expand(N, Cc, H, W)          # a stride-0 view: nothing is materialised here
+
+
+class _SEGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        lib = _lib.load()
+        _dev(x, "x", dtype=None, contiguous=False)
+        _dev(s, "s", dtype=None, contiguous=False)
+        if x.dim() != 4 or x.dtype not in _DT_CODES or s.numel() != x.shape[0] * x.shape[1]:
+            raise ValueError(f"se_gate: x {tuple(x.shape)} {x.dtype}, s {tuple(s.shape)}")
+        x = x.contiguous()
+        s = s.to(x.dtype).contiguous()
+        N, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        check(lib.moma_se_gate_fwd(_ptr(x), _ptr(s), _ptr(out), N * Cc, H * W, _DT_CODES[x.dtype], _stream()), "moma_se_gate_fwd")
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, s = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dout = dout.contiguous()
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        dx = torch.empty_like(x)
+        ds = torch.empty_like(s)
+        check(lib.moma_se_gate_bwd(_ptr(x), _ptr(s), _ptr(dout), _ptr(dx), _ptr(ds), N * Cc, H * W, _DT_CODES[x.dtype],
+                                   _stream()), "moma_se_gate_bwd")
+        return dx, ds
+
+
+def plane_mean(x):
+    """[N,C,H,W] -> [N,C,1,1] mean over each plane (F.adaptive_avg_pool2d(x, 1))."""
+    return _PlaneMean.apply(x)
+
+
+def se_gate(x, s):
+    """x * sigmoid(s) with s [N,C,1,1]."""
+    return _SEGate.apply(x, s)
