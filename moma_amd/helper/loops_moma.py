@@ -15,6 +15,7 @@ from __future__ import print_function
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -148,16 +149,47 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
     return float(top1.avg), float(losses.avg)
 
 
-def validate_distill(val_loader, model, criterion, opt):
-    """Evaluation of the student: (top-1 %, mean loss)   (reference :448-529, metrics only)."""
-    losses, top1 = AverageMeter(), AverageMeter()
-    model.eval()
+def macro_f1(conf_mat):
+    """Mean per-class F1 from a confusion matrix (rows = true, columns = predicted); a class with no true positive
+    counts 0 (reference train_student_moma.py:522-531)."""
+    cm = np.asarray(conf_mat, dtype=np.float64)
+    f = 0.0
+    for i in range(cm.shape[0]):
+        if cm[i, i] > 0:
+            prec, rec = float(cm[i, i] / cm[:, i].sum()), float(cm[i, i] / cm[i, :].sum())
+            f += 2 * prec * rec / (prec + rec)
+    return float(f / cm.shape[0])
+
+
+def validate_distill(val_loader, module_list, criterion, opt, prefix="Test"):
+    """Evaluation of the student (reference :448-529): returns (top-1 %, mean loss, {'acc', 'conf_mat'}).
+    The confusion matrix is accumulated on the GPU (one bincount per batch) instead of gathering all logits on the
+    host; under DDP the sums, counts and the matrix are summed over the ranks as in the reference (:512-527)."""
+    model = module_list[0] if isinstance(module_list, (list, tuple, torch.nn.ModuleList)) else module_list
+    for m in (module_list if isinstance(module_list, (list, tuple, torch.nn.ModuleList)) else [module_list]):
+        m.eval()
+    n_cls = int(opt.n_cls)
     dev = next(model.parameters()).device
+    conf = torch.zeros(n_cls * n_cls, dtype=torch.int64, device=dev)
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)          # top-1 sum, loss sum, count, count
     with torch.no_grad():
-        for images, labels in val_loader:
+        for idx, (images, labels) in enumerate(val_loader):
             images = images.to(dev, non_blocking=True)
             labels = labels.to(dev, non_blocking=True)
             output = model(images).float()
-            losses.update(criterion(output, labels).detach(), images.size(0))
-            top1.update(accuracy(output, labels, topk=(1,))[0].squeeze(0), images.size(0))
-    return float(top1.avg), float(losses.avg)
+            n = images.size(0)
+            pred = output.argmax(dim=1)
+            sums[0] += (pred == labels).sum() * 100.0
+            sums[1] += criterion(output, labels).detach().double() * n
+            sums[2] += n
+            conf += torch.bincount(labels * n_cls + pred, minlength=n_cls * n_cls)
+            if idx % opt.print_freq == 0 and idx > 0:
+                s = sums.tolist()
+                print("{}: [{}/{}]\tGPU: {}\tLoss {:.4f}\tAcc@1 {:.3f}".format(prefix, idx, len(val_loader), opt.gpu,
+                                                                              s[1] / s[2], s[0] / s[2]))
+    if getattr(opt, "multiprocessing_distributed", False) and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(sums)
+        torch.distributed.all_reduce(conf)
+    s = sums.tolist()
+    acc, loss = s[0] / max(s[2], 1.0), s[1] / max(s[2], 1.0)
+    return acc, loss, {"acc": acc, "conf_mat": conf.view(n_cls, n_cls).cpu().numpy()}

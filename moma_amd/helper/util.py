@@ -3,6 +3,7 @@
 from __future__ import print_function
 
 import json
+import os
 
 import numpy as np
 import torch
@@ -63,6 +64,16 @@ def reduce_tensor(tensor, world_size=1, op="avg"):
 def save_dict_to_json(d, json_path):
     with open(json_path, "w") as f:
         json.dump(d, f, indent=4, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+
+
+def update_dict_to_json(epoch, d, json_path):
+    """Add `d` under key `epoch` to the json file (created on first use) -- reference helper/util.py:87-107."""
+    data = {}
+    if os.path.isfile(json_path):
+        with open(json_path) as f:
+            data = json.load(f)
+    data[str(epoch)] = d
+    save_dict_to_json(data, json_path)
 
 
 def load_json_to_dict(json_path):

@@ -32,8 +32,8 @@ from .MoMA.mem_moco import build_mem
 from .MoMA.criterion_moco_att import CMO
 from .dataset.synthetic import SyntheticLoader
 from .distiller_zoo import DistillKL
-from .helper.loops_moma import train_distill_moma, validate_distill
-from .helper.util import adjust_learning_rate, reduce_tensor, save_dict_to_json
+from .helper.loops_moma import macro_f1, train_distill_moma, validate_distill
+from .helper.util import adjust_learning_rate, reduce_tensor, save_dict_to_json, update_dict_to_json
 from .learning.contrast_trainer import ContrastTrainer
 from .model_def import load_model
 from .backbones import model_dict
@@ -238,7 +238,7 @@ def main_worker(gpu, ngpus_per_node, opt):
     if is_main:
         os.makedirs(opt.save_folder, exist_ok=True)
         trainer.args.tb_folder = opt.tb_folder
-    best_acc, t_total = 0.0, time.time()
+    best_acc, best_f1, t_total = 0.0, 0.0, time.time()
     start_epoch = 1
     if opt.resume:
         ck = torch.load(opt.resume, map_location=device)
@@ -248,7 +248,7 @@ def main_worker(gpu, ngpus_per_node, opt):
         if contrast is not None and ck.get("contrast") is not None:
             contrast.load_state_dict(ck["contrast"])
         optimizer.load_state_dict(ck["optimizer"])
-        best_acc, start_epoch = ck.get("best_acc", 0.0), ck["epoch"] + 1
+        best_acc, best_f1, start_epoch = ck.get("best_acc", 0.0), ck.get("best_f1", 0.0), ck["epoch"] + 1
         print("==> resumed from {} (epoch {}, queue pointer {})".format(
             opt.resume, ck["epoch"], contrast.index if contrast is not None else "-"))
     for epoch in range(start_epoch, opt.epochs + 1):
@@ -266,19 +266,36 @@ def main_worker(gpu, ngpus_per_node, opt):
             ips = opt.steps_per_epoch * opt.batch_size * max(1, getattr(opt, "world_size", 1)) / (t2 - t1)
             print(" * Epoch {}, Acc@1 {:.3f}, Loss {:.4f}, Time {:.2f}, {:.1f} images/sec".format(
                 epoch, train_acc, train_loss, t2 - t1, ips))
-        val_acc, val_loss = validate_distill(val_loader, model_s, criterion_list[0], opt)
+        val_acc, val_loss, val_stat = validate_distill(val_loader, module_list, criterion_list[0], opt, prefix="Val")
+        test_acc = test_loss = test_stat = None
+        if not opt.skip_test:                                    # reference :515-519 (the synthetic set doubles as test)
+            test_acc, test_loss, test_stat = validate_distill(val_loader, module_list, criterion_list[0], opt, prefix="Test")
         if is_main:
-            print(" ** Acc_val@1 {:.3f}".format(val_acc))
+            val_f1 = macro_f1(val_stat["conf_mat"])               # model selection by accuracy AND by macro-F1 (:522-571)
+            print(" ** Acc_val@1 {:.3f}  F1_val {:.4f}".format(val_acc, val_f1))
+            if test_acc is not None:
+                print(" ** Acc_test@1 {:.3f}".format(test_acc))
+            state = {"epoch": epoch, "model": model_s.state_dict(), "best_acc": best_acc,
+                     "optimizer": optimizer.state_dict()}
             if val_acc > best_acc:
                 best_acc = val_acc
-                state = {"epoch": epoch, "model": model_s.state_dict(), "best_acc": best_acc,
-                         "best_acc_epoch": epoch, "optimizer": optimizer.state_dict()}
+                state.update(best_acc=best_acc, best_acc_epoch=epoch)
+                print("saving the best acc model!")
                 torch.save(state, os.path.join(opt.save_folder, "net_best_acc.pth"))
+            if val_f1 > best_f1:
+                best_f1 = val_f1
+                state.update(best_f1=best_f1, best_f1_epoch=epoch)
+                print("saving the best f1 model!")
+                torch.save(state, os.path.join(opt.save_folder, "net_best_f1.pth"))
+            metrics = {"val_cf": val_stat["conf_mat"].tolist(), "val_loss": val_loss, "val_acc": val_acc}
+            if test_stat is not None:
+                metrics.update(test_cf=test_stat["conf_mat"].tolist(), test_loss=test_loss, test_acc=test_acc)
+            update_dict_to_json(epoch, metrics, os.path.join(opt.save_folder, "stat.json"))
             # full training state (the reference saves the student only): enough to resume bit-for-bit
             torch.save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
                         "criterion_kd": criterion_list[2].state_dict(),
                         "contrast": contrast.state_dict() if contrast is not None else None,
-                        "optimizer": optimizer.state_dict(), "best_acc": best_acc},
+                        "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1},
                        os.path.join(opt.save_folder, "ckpt_last.pth"))
     if is_main:
         print("best accuracy:", best_acc)

@@ -53,3 +53,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.MomaHipError):
         _lib.load()
+
+
+def test_macro_f1_matches_reference_formula():
+    """Model selection metric of the epoch loop (reference train_student_moma.py:522-531)."""
+    import numpy as np
+    from moma_amd.helper.loops_moma import macro_f1
+    cm = np.array([[5, 1, 0], [2, 3, 0], [0, 0, 0]])
+    f0 = 2 * (5 / 7) * (5 / 6) / ((5 / 7) + (5 / 6))
+    f1 = 2 * (3 / 4) * (3 / 5) / ((3 / 4) + (3 / 5))
+    assert abs(macro_f1(cm) - (f0 + f1) / 3) < 1e-12          # a class without true positives counts 0
+    assert macro_f1(np.eye(4) * 7) == 1.0

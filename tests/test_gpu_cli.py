@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -24,7 +25,11 @@ def test_cli_trains_on_synthetic(tmp_path, extra):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "images/sec" in r.stdout and "best accuracy" in r.stdout
     saved = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs]
-    assert any(f.endswith("net_best_acc.pth") for f in saved)
+    assert any(f.endswith("net_best_acc.pth") for f in saved) and any(f.endswith("net_best_f1.pth") for f in saved)
+    stat = [f for f in saved if f.endswith("stat.json")]
+    st = json.load(open(stat[0]))                                       # per-epoch confusion matrices (reference :573-591)
+    assert sorted(st) == ["1", "2"] and np.array(st["2"]["val_cf"]).shape == (2, 2)
+    assert abs(np.trace(np.array(st["2"]["val_cf"])) / np.sum(st["2"]["val_cf"]) * 100 - st["2"]["val_acc"]) < 1e-6
     params = [f for f in saved if f.endswith("parameters.json")]
     assert params and json.load(open(params[0]))["nce_t"] == 0.15       # forced for --distill moma (reference :135)
 
