@@ -221,6 +221,10 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     if (db_proj) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
     g = gemm(dy, w_proj, dA, N, d, d, d, d, d, 0, 1, 1.f, prec);
     MOMA_TRY(launch_gemm(g, st));
+    if (mha_core_fused_supported(N, d, H, prec)) {
+        // fused per-head backward core: D = rowdot(dA, a) in the dP scratch, then dQ | dK | dV in two launches
+        MOMA_TRY(launch_mha_core_bwd(qkv, probs, attn_out, dA, dP, dqkv, N, d, H, st));
+    } else {
     // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
     g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
     g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
@@ -238,6 +242,7 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
     g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
     MOMA_TRY(launch_gemm(g, st));
+    }
     // qkv linear: dWqkv = dqkv^T x ; dbqkv = colsum(dqkv) ; dx = dqkv Wqkv
     if (dw_qkv) {
         g = gemm(dqkv, x, dw_qkv, 3 * d, d, N, 3L * d, d, d, 1, 1, 1.f, prec);

@@ -234,12 +234,194 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
         if (q0 + row < N && col < hd) *reinterpret_cast<float4*>(&attn_out[(long)(q0 + row) * d + head * hd + col]) = acc;
     }
 }
+
+// =====================================================================================================
+// Backward of the per-head core (bf16 policy), replacing four GEMM launches and the softmax-backward kernel:
+//   D_i  = sum_c dA[i,c] * O[i,c]                  (mha_rowdot_kernel, per head)
+//   dP   = dA_h V_h^T ;  dS = P o (dP - D) * scale
+//   dQ   = dS K ;  dK = dS^T Q ;  dV = P^T dA_h
+// Same shape as the forward: operands go global -> registers -> MFMA directly, a workgroup's waves split the
+// reduction tiles and their partial results are summed through LDS.  Two roles of one kernel:
+//   ROLE_Q  : workgroup = (head, 32 queries); loop over key tiles; tile X[key, q] = V_tile . dA_blk^T has the query on
+//             the lane (exactly the forward's score tile), P / dS likewise; dQ += dS . K_tile.
+//   ROLE_KV : workgroup = (head, 32 keys);    loop over query tiles; the tile is built transposed,
+//             X'[q, key] = dA_tile . V_blk^T, so that the key sits on the lane: dV += P'^T-as-A . dA_tile and
+//             dK += dS'-as-A . Q_tile use it as the MFMA A operand [key, q] without any data movement.
+// The k index of the second product enumerates the tile's rows in the order the tile registers hold them
+// (register 8s + j <-> row 16s + 8*(j>>2) + 4*h2 + (j&3)), as in the forward.
+constexpr int BW = 4;                         // waves per workgroup in the backward (512 registers per lane each)
+
+__global__ __launch_bounds__(256) void mha_rowdot_kernel(const float* __restrict__ dA, const float* __restrict__ O,
+                                                         float* __restrict__ D, int N, int d, int H) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // item = head * N + row
+    if (item >= N * H) return;
+    const int head = item / N, row = item - head * N, hd = d / H;
+    const float* a = dA + (long)row * d + head * hd;
+    const float* o = O + (long)row * d + head * hd;
+    float sacc = 0.f;
+    for (int c = lane; c < hd; c += 64) sacc = fmaf(a[c], o[c], sacc);
+    sacc = wave_sum(sacc);
+    if (lane == 0) D[item] = sacc;
+}
+
+// B operand of the second product from a row-major [rows, ld] matrix: lane (col n, h2) takes, for k-step s, the 8 rows
+// row0 + 16s + 8*(j>>2) + 4*h2 + (j&3) of column col0 + 32c + n (every load instruction covers two 128-B row segments)
+__device__ __forceinline__ void load_strided(float (&vv)[NCT][2][8], const float* __restrict__ base, long ld, int row0,
+                                             int N, int hd, int n, int h2) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = row0 + 16 * s2 + 8 * (j >> 2) + 4 * h2 + (j & 3), col = 32 * c + n;
+                vv[c][s2][j] = base[(long)min(row, N - 1) * ld + min(col, hd - 1)];
+            }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = row0 + 16 * s2 + 8 * (j >> 2) + 4 * h2 + (j & 3), col = 32 * c + n;
+                asm volatile("" : "+v"(vv[c][s2][j]));     // keep the loads unconditional (see the forward)
+                vv[c][s2][j] = (row < N && col < hd) ? vv[c][s2][j] : 0.f;
+            }
+}
+
+// acc[c] += A(tile registers t, as [lane-row, k]) . B(vv)
+__device__ __forceinline__ void tile_product(f32x16 (&acc)[NCT], const f32x16& t, const float (&vv)[NCT][2][8]) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pa = bf16x8{(__bf16)t[8 * s2 + 0], (__bf16)t[8 * s2 + 1], (__bf16)t[8 * s2 + 2], (__bf16)t[8 * s2 + 3],
+                                 (__bf16)t[8 * s2 + 4], (__bf16)t[8 * s2 + 5], (__bf16)t[8 * s2 + 6], (__bf16)t[8 * s2 + 7]};
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const bf16x8 vb = bf16x8{(__bf16)vv[c][s2][0], (__bf16)vv[c][s2][1], (__bf16)vv[c][s2][2], (__bf16)vv[c][s2][3],
+                                     (__bf16)vv[c][s2][4], (__bf16)vv[c][s2][5], (__bf16)vv[c][s2][6], (__bf16)vv[c][s2][7]};
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, acc[c], 0, 0, 0);
+        }
+    }
+}
+
+// sum the BW waves' accumulators through LDS and store rows [r0, r0+32) x hd of `out` (row stride ld, column offset in `out`)
+__device__ __forceinline__ void reduce_store(float* s_o, const f32x16 (&acc)[NCT], float* __restrict__ out, long ld, int r0,
+                                             int N, int hd, int tid, int wave, int n, int h2) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_o[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2) * DP + 32 * c + n] = acc[c][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 1024 / (BW * 64); ++i) {
+        const int idx = tid + i * BW * 64;
+        const int row = idx >> 5, col = (idx & 31) * 4;
+        float4 a = *reinterpret_cast<const float4*>(&s_o[row * DP + col]);
+#pragma unroll
+        for (int w = 1; w < BW; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(&s_o[(w * 32 + row) * DP + col]);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (r0 + row < N && col < hd) *reinterpret_cast<float4*>(&out[(long)(r0 + row) * ld + col]) = a;
+    }
+    __syncthreads();
+}
+
+template <bool ROLE_KV>
+__global__ __launch_bounds__(BW * 64) void mha_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                             const float* __restrict__ dA, const float* __restrict__ Dv,
+                                                             float* __restrict__ dqkv, int N, int d, int H) {
+    __shared__ __attribute__((aligned(16))) float s_o[BW * 32 * DP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h2 = lane >> 5;
+    const int head = blockIdx.y, hd = d / H;
+    const int b0 = blockIdx.x * 32;                         // this workgroup's 32 queries (ROLE_Q) or keys (ROLE_KV)
+    const long ld = 3L * d;
+    const float* qb = qkv + head * hd;
+    const float* kb = qkv + d + head * hd;
+    const float* vb = qkv + 2 * d + head * hd;
+    const float* dab = dA + head * hd;
+    const float* P = probs + (long)head * N * N;
+    const float* Dh = Dv + (long)head * N;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int ntiles = (N + KT - 1) / KT;
+
+    bf16x8 res[KS];                                         // resident B fragments: dA rows of the block / V rows of the block
+    if constexpr (!ROLE_KV) load_row_frags(res, dab, d, b0 + n, N, hd, h2, 1.f);
+    else load_row_frags(res, vb, ld, b0 + n, N, hd, h2, 1.f);
+    f32x16 acc0[NCT], acc1[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
+    const float Dn = (!ROLE_KV && b0 + n < N) ? Dh[b0 + n] : 0.f;          // ROLE_Q: D of the lane's query
+
+    for (int t = wave; t < ntiles; t += BW) {
+        const int t0 = t * KT;
+        // tile X = (rows of the tile as A) . (block as B): ROLE_Q: V_tile . dA_blk^T = dP[key, q];  ROLE_KV: dA_tile . V_blk^T
+        bf16x8 af[KS];
+        if constexpr (!ROLE_KV) load_row_frags(af, vb, ld, t0 + n, N, hd, h2, 1.f);
+        else load_row_frags(af, dab, d, t0 + n, N, hd, h2, 1.f);
+        f32x16 x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], res[ks], x, 0, 0, 0);
+        // P of the tile in the same layout (tile row on the registers, block element on the lane), dS = P (dP - D) scale
+        f32x16 p, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tr = t0 + (r & 3) + 8 * (r >> 2) + 4 * h2;        // tile row of register r
+            const int qi = ROLE_KV ? tr : b0 + n, kj = ROLE_KV ? b0 + n : tr;
+            float pv = P[(long)min(qi, N - 1) * N + min(kj, N - 1)];
+            asm volatile("" : "+v"(pv));
+            p[r] = (qi < N && kj < N) ? pv : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float dq_;
+            if constexpr (ROLE_KV) {
+                const int qi = t0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                dq_ = Dh[min(qi, N - 1)];
+            } else {
+                dq_ = Dn;
+            }
+            ds[r] = p[r] * (x[r] - dq_) * scale;
+        }
+        float vv[NCT][2][8];
+        if constexpr (!ROLE_KV) {
+            load_strided(vv, kb, ld, t0, N, hd, n, h2);                  // dQ += dS . K_tile
+            tile_product(acc0, ds, vv);
+        } else {
+            load_strided(vv, dab, d, t0, N, hd, n, h2);                  // dV += P' . dA_tile
+            tile_product(acc1, p, vv);
+            load_strided(vv, qb, ld, t0, N, hd, n, h2);                  // dK += dS' . Q_tile
+            tile_product(acc0, ds, vv);
+        }
+    }
+    if constexpr (!ROLE_KV) {
+        reduce_store(s_o, acc0, dqkv + head * hd, ld, b0, N, hd, tid, wave, n, h2);
+    } else {
+        reduce_store(s_o, acc0, dqkv + d + head * hd, ld, b0, N, hd, tid, wave, n, h2);
+        reduce_store(s_o, acc1, dqkv + 2 * d + head * hd, ld, b0, N, hd, tid, wave, n, h2);
+    }
+}
 }  // namespace
 
 bool mha_core_fused_supported(int N, int d, int H, int prec) {
     if (prec != MOMA_PREC_BF16 || H <= 0 || d % H) return false;
     const int hd = d / H;
     return hd % 16 == 0 && hd <= DP && d % 4 == 0 && N >= 1;
+}
+
+// D scratch: H*N floats.  dqkv [N,3d] receives dQ | dK | dV of every head.
+hipError_t launch_mha_core_bwd(const float* qkv, const float* probs, const float* attn_out, const float* dA, float* D,
+                               float* dqkv, int N, int d, int H, hipStream_t st) {
+    hipLaunchKernelGGL(mha_rowdot_kernel, dim3((N * H + 3) / 4), dim3(256), 0, st, dA, attn_out, D, N, d, H);
+    const dim3 grid((N + 31) / 32, H), block(BW * 64);
+    hipLaunchKernelGGL((mha_core_bwd_kernel<false>), grid, block, 0, st, qkv, probs, dA, D, dqkv, N, d, H);
+    hipLaunchKernelGGL((mha_core_bwd_kernel<true>), grid, block, 0, st, qkv, probs, dA, D, dqkv, N, d, H);
+    return hipGetLastError();
 }
 
 hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* probs, int N, int d, int H, hipStream_t st) {

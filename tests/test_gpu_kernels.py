@@ -296,6 +296,31 @@ def test_mha_fused_core_no_grad(ops, N, d, H):
     assert err < 3e-2, err
 
 
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (33, 128, 8), (129, 256, 2), (300, 512, 4), (77, 192, 4), (64, 64, 4)])
+def test_mha_fused_bwd_peaked(ops, N, d, H):
+    """Fused per-head backward core (bf16 policy): peaked softmax rows (large q / k weights) so that a wrong pairing of
+    tile rows between the two MFMA products of dQ / dK / dV cannot hide behind near-uniform attention; ragged N, head
+    dims 16 ... 128; all five parameter gradients and dx against the fp64 oracle."""
+    rng = np.random.default_rng(N * 3 + d)
+    x = O.l2_normalize(rng.standard_normal((N, d)).astype(np.float32))
+    bound = 1.0 / np.sqrt(d)
+    w_qkv = rng.uniform(-bound, bound, (3 * d, d)).astype(np.float32) * 4
+    w_qkv[:2 * d] *= 5
+    b_qkv = rng.uniform(-bound, bound, 3 * d).astype(np.float32)
+    w_proj = rng.uniform(-bound, bound, (d, d)).astype(np.float32)
+    b_proj = rng.uniform(-bound, bound, d).astype(np.float32)
+    dy = rng.standard_normal((N, d)).astype(np.float32)
+    ref = O.attention_bwd(x, w_qkv, b_qkv, w_proj, b_proj, H, dy, dtype=np.float64)
+    tx = _t(x).requires_grad_(True)
+    tw = [_t(a).requires_grad_(True) for a in (w_qkv, b_qkv, w_proj, b_proj)]
+    y = ops.mha(tx, *tw, H, "bf16")
+    (y * _t(dy)).sum().backward()
+    for t, nm in zip([y.detach()] + [a.grad for a in [tx] + tw], ("y", "dx", "d_wqkv", "d_bqkv", "d_wproj", "d_bproj")):
+        r = ref[nm]
+        err = np.abs(t.cpu().numpy() - r).max() / max(np.abs(r).max(), 1e-12)
+        assert err < 4e-2, (nm, err)
+
+
 # ------------------------------------------------------------------------------------------------ ABI
 def test_abi_argument_checks(ops):
     from moma_amd import _lib
