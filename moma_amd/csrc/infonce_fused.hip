@@ -691,7 +691,7 @@ FlashPlan plan(int B, int K) {
 
 bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec) {
     if (prec != MOMA_PREC_BF16 || qdtype != MOMA_DT_BF16) return false;
-    if (d != 256 && d != 384 && d != 512) return false;
+    if (d != 128 && d != 256 && d != 384 && d != 512) return false;
     return B >= 1 && K >= 1;
 }
 
@@ -725,6 +725,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         MOMA_SET_LDS(512, true, false); MOMA_SET_LDS(512, true, true); MOMA_SET_LDS(512, false, false); MOMA_SET_LDS(512, false, true);
         MOMA_SET_LDS(384, true, false); MOMA_SET_LDS(384, true, true); MOMA_SET_LDS(384, false, false); MOMA_SET_LDS(384, false, true);
         MOMA_SET_LDS(256, true, false); MOMA_SET_LDS(256, true, true); MOMA_SET_LDS(256, false, false); MOMA_SET_LDS(256, false, true);
+        MOMA_SET_LDS(128, true, false); MOMA_SET_LDS(128, true, true); MOMA_SET_LDS(128, false, false); MOMA_SET_LDS(128, false, true);
 #undef MOMA_SET_LDS
         attr_done = true;
     }
@@ -745,7 +746,8 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     } while (0)
     if (d == 512) MOMA_FLASH_LAUNCH(512);
     else if (d == 384) MOMA_FLASH_LAUNCH(384);
-    else MOMA_FLASH_LAUNCH(256);
+    else if (d == 256) MOMA_FLASH_LAUNCH(256);
+    else MOMA_FLASH_LAUNCH(128);
 #undef MOMA_FLASH_LAUNCH
 #undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
