@@ -72,13 +72,15 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >>
 //   = [rg*4*D*2 + seg*256]  (wave-uniform, scalar)  +  lane term  (1 VGPR, computed once per kernel)
 //   Every piece of wave w has rg & 3 == w (pc = 4i + w), so a wave needs a single lane term.
 struct DmaLane {
-    unsigned term;        // (L>>4)*D*2 + ((L&15) ^ swz(4*w + (L>>4)))*16
+    unsigned term;        // (L>>4)*pitch + ((L&15) ^ swz(4*w + (L>>4)))*16
+    unsigned pitch;       // bytes between queue rows: D*2, or the full row when the tile is a column slab of a wider queue
 };
 template <int D>
-__device__ __forceinline__ DmaLane dma_lane_terms(int lane, int wave) {
+__device__ __forceinline__ DmaLane dma_lane_terms(int lane, int wave, unsigned pitch) {
     DmaLane t;
     const int rl = lane >> 4, sl = lane & 15;
-    t.term = (unsigned)(rl * (D * 2) + ((sl ^ swz(4 * wave + rl)) << 4));
+    t.pitch = pitch;
+    t.term = (unsigned)(rl * pitch + ((sl ^ swz(4 * wave + rl)) << 4));
     return t;
 }
 template <int D, bool PARTIAL = true>
@@ -86,14 +88,14 @@ __device__ __forceinline__ void dma_piece(int i, const DmaLane& dl, const bf16_r
                                           char* buf, int wave, int lane) {
     const int pc = i * 4 + wave;                // wave-uniform
     const int seg = pc >> 3, rg = pc & 7;
-    const char* tile = reinterpret_cast<const char*>(queue) + key0 * (long)(D * 2) + seg * 256;   // wave-uniform
+    const char* tile = reinterpret_cast<const char*>(queue) + key0 * (long)dl.pitch + seg * 256;   // wave-uniform
     unsigned off = dl.term;
     if (PARTIAL && key0 + KT > K) {             // queue's last, partial tile: clamp rows past K (masked later)
         const int rl = lane >> 4;
         const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
-        off = off - (unsigned)(rl * (D * 2)) + (unsigned)row * (unsigned)(D * 2);
+        off = off - (unsigned)rl * dl.pitch + (unsigned)row * dl.pitch;
     } else {
-        tile += rg * 4 * (D * 2);
+        tile += rg * 4 * (long)dl.pitch;
     }
     char* dst = buf + seg * 8192 + rg * 1024;   // wave-uniform LDS base; lane L lands at +16*L
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + off),
@@ -140,13 +142,28 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
 //   2^OVERFLOW_THR above m raises flag[chunk][wave-of-rows]; its partials are then invalid.  (m = first-tile max + REF_MARGIN)
 // REPAIR = true : second launch of the same grid; workgroups without a raised flag exit at once, flagged
 //   waves redo their chunk with m = the true chunk max the first launch recorded (x_part) -- cannot overflow.
-template <int D, bool WITH_DQ, bool REPAIR>
+// MODE 0: the one-pass kernel described above (d = D).
+// MODE 1 / 2: wide queues (d > 512) go through column SLABS of D <= 512 columns of the same key tiles, with the complete
+//   score tiles kept in a scratch `xs` in register order (xs[((row-wave * ntiles + tile) * 64 + lane) * 16 + r]):
+//   MODE 1 adds this slab's partial scores to the scratch (first slab: stores), nothing else;
+//   MODE 2 reads the finished scores, forms normalised P = 2^(x - lse2) and accumulates this slab's columns of O.
+//   `queue` then points at the slab's first column and `slab` carries the row pitch and the first-slab flag.
+struct SlabArgs {
+    float* xs;
+    const float* lse;     // [B] natural-log lse of the complete logits (MODE 2)
+    unsigned pitch;       // bytes between queue rows
+    int first;            // MODE 1: this is the first slab (store instead of accumulate)
+};
+template <int D, bool WITH_DQ, bool REPAIR, int MODE = 0>
 __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, const uint4* __restrict__ qpack,
                                                    const bf16_raw* __restrict__ queue, int B, int K, int nbt,
                                                    int nchunk, int tiles_per_chunk, int Bpad,
                                                    unsigned* __restrict__ o_part, float* __restrict__ m_part,
                                                    float* __restrict__ l_part, float* __restrict__ x_part,
-                                                   int* __restrict__ ovf_flag) {
+                                                   int* __restrict__ ovf_flag, SlabArgs slab = SlabArgs{}) {
+    static_assert(MODE == 0 || !REPAIR, "slab passes have no repair launch");
+    static_assert(MODE != 1 || !WITH_DQ, "score slabs carry no O");
+    static_assert(MODE != 2 || WITH_DQ, "P.K slabs carry O");
     constexpr int KS = D / 16;       // k-steps of the score product
     constexpr int NCT = D / 32;      // 32-column tiles of O
     constexpr int TILE_BYTES = KT * D * 2;
@@ -174,13 +191,14 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const int ntiles = (K + KT - 1) / KT;
     const int t0 = chunk * tiles_per_chunk;
     const int t1 = min(t0 + tiles_per_chunk, ntiles);
-    const DmaLane dl = dma_lane_terms<D>(lane, wave);
+    const DmaLane dl = dma_lane_terms<D>(lane, wave, MODE == 0 ? (unsigned)(D * 2) : slab.pitch);
     // partial slot of this wave's 32 query rows in chunk `chunk`
     const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
     int* my_flag = ovf_flag + ((long)chunk * nbt + bt) * 4;      // 4 ints per workgroup, one per wave
 
     bool active = true;
     float m_ref = NEG_BIG;
+    if constexpr (MODE == 2) m_ref = slab.lse[min(bt * QROWS_WG + wave * 32 + n, B - 1)] * 1.4426950408889634f;
     if constexpr (REPAIR) {
         const int f0 = my_flag[0], f1 = my_flag[1], f2 = my_flag[2], f3 = my_flag[3];
         if ((f0 | f1 | f2 | f3) == 0) return;                    // workgroup-uniform
@@ -191,7 +209,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // ---- Q fragments: B operand of X = K.Q^T ; lane (q=n, h) holds Q[q][16ks + 8h + j], pre-scaled by log2e/T,
     //      pre-packed in fragment order by infonce_qpack_kernel (coalesced 16 B per lane)
     bf16x8 qf[KS];
-    {
+    if constexpr (MODE != 2) {
         const uint4* qp = qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qp[ks * 64]);
@@ -408,7 +426,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     wait_tiles_in_flight(min(t1 - t0, NBUF - 1) - 1);
     __builtin_amdgcn_s_barrier();
 
-    if constexpr (WITH_DQ && !REPAIR) {
+    if constexpr (WITH_DQ && !REPAIR && MODE == 0) {
         // ---- software-pipelined main loop (one wave per SIMD: nothing else hides the softmax's VALU time):
         //   iteration t:  X(t+1) = scores of tile t+1            [matrix pipe; DMA pieces of tile t+3 in its shadow]
         //                 O += P(t).K(t)  ||  P(t+1) = softmax numerators of X(t+1), one register per column tile
@@ -488,8 +506,37 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll 1
         for (int t = t0; t < t1; ++t) {
             const bool refill = t + NBUF - 1 < t1;
-            if (!active && refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
-            if (active) {
+            if (MODE == 0 && !active && refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
+            if constexpr (MODE != 0) {
+                // slab passes: the tile's complete scores live in the scratch, 16 floats per lane in register order
+                float4* xa = reinterpret_cast<float4*>(slab.xs + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 16);
+                f32x16 x;
+                if constexpr (MODE == 1) {
+                    score_dispatch(slot(t), x, 0.f, refill, t + NBUF - 1);
+                    if (!slab.first) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const float4 v = xa[g4];
+                            x[4 * g4] += v.x; x[4 * g4 + 1] += v.y; x[4 * g4 + 2] += v.z; x[4 * g4 + 3] += v.w;
+                        }
+                    }
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) xa[g4] = make_float4(x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]);
+                } else {
+                    if (refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 v = xa[g4];
+                        x[4 * g4] = v.x; x[4 * g4 + 1] = v.y; x[4 * g4 + 2] = v.z; x[4 * g4 + 3] = v.w;
+                    }
+                    mask_tail(x, t);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);      // m_ref = the row's lse (log2)
+                    bf16x8 pa[2];
+                    pack(x, pa);
+                    pv(slot(t), pa, [&](int) __attribute__((always_inline)) {});
+                }
+            } else if (active) {
                 f32x16 x;
                 score_dispatch(slot(t), x, 0.f, refill, t + NBUF - 1);
                 softmax_plain(x, t, t == t0);
@@ -508,12 +555,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (h == 0) {
+        if (MODE == 0 && h == 0) {
             m_part[prow + n] = m_ref;
             l_part[prow + n] = l_tot;
             if constexpr (!REPAIR) x_part[prow + n] = mx;
         }
-        if constexpr (!REPAIR) {
+        if constexpr (!REPAIR && MODE == 0) {
             const int any = __any(ovf) ? 1 : 0;
             if (lane == 0) {
                 my_flag[wave] = any;
@@ -556,6 +603,115 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const uint4* __re
     } else {
         infonce_flash_body<D, WITH_DQ, false>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
                                               o_part, m_part, l_part, x_part, ovf_flag);
+    }
+}
+
+// ---- wide queues (d > 512): slab passes ------------------------------------------------------------------------
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __restrict__ qpack, const bf16_raw* __restrict__ queue,
+                                                              int B, int K, int nbt, int nchunk, int tiles_per_chunk, int Bpad,
+                                                              unsigned* __restrict__ o_part, SlabArgs slab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    infonce_flash_body<D, MODE == 2, false, MODE>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
+                                                  o_part, nullptr, nullptr, nullptr, nullptr, slab);
+}
+
+// Q columns [col0, col0 + D) of q [B, dfull] -> fragment order (as infonce_qpack_kernel, which is the col0 = 0, dfull = D case)
+template <int D>
+__global__ __launch_bounds__(256) void infonce_qpack_slab_kernel(const float* __restrict__ q, int B, int dfull, int col0,
+                                                                 float scale_log2, uint4* __restrict__ qpack, int n_row_tiles) {
+    constexpr int KS = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_row_tiles * KS) return;
+    const int rt = item / KS, ks = item % KS;
+    const int row = rt * 32 + (lane & 31), h = lane >> 5;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < B) {
+        const float* qp = q + (long)row * dfull + col0 + 16 * ks + 8 * h;
+        a = *reinterpret_cast<const float4*>(qp);
+        b = *reinterpret_cast<const float4*>(qp + 4);
+    }
+    const bf16x8 f = bf16x8{(__bf16)(a.x * scale_log2), (__bf16)(a.y * scale_log2), (__bf16)(a.z * scale_log2),
+                            (__bf16)(a.w * scale_log2), (__bf16)(b.x * scale_log2), (__bf16)(b.y * scale_log2),
+                            (__bf16)(b.z * scale_log2), (__bf16)(b.w * scale_log2)};
+    qpack[(long)item * 64 + lane] = __builtin_bit_cast(uint4, f);
+}
+
+// softmax statistics of the finished score scratch: wave = (row-wave rw, split of the key tiles); online max per lane,
+// halves merged at the end; writes (m, l, true max) in the partial format of the one-pass kernel (chunk = split)
+__global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __restrict__ xs, int K, int ntiles, int Bpad,
+                                                                 int nsplit, float* __restrict__ m_part,
+                                                                 float* __restrict__ l_part, float* __restrict__ x_part) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nrw = Bpad / 32;
+    if (item >= nrw * nsplit) return;
+    const int rw = item / nsplit, split = item - rw * nsplit;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    const int tb = split * per, te = min(tb + per, ntiles);
+    float m = NEG_BIG, l = 0.f;
+    for (int t = tb; t < te; ++t) {
+        const float4* xa = reinterpret_cast<const float4*>(xs + (((long)rw * ntiles + t) * 64 + lane) * 16);
+        float x[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 v = xa[g4];
+            x[4 * g4] = v.x; x[4 * g4 + 1] = v.y; x[4 * g4 + 2] = v.z; x[4 * g4 + 3] = v.w;
+        }
+        if ((t + 1) * KT > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
+        }
+        float tm = x[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, x[r]);
+        const float mn = fmaxf(m, tm);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += exp2f(x[r] - mn);
+        l = l * exp2f(m - mn) + ps;
+        m = mn;
+    }
+    const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+    const float M = fmaxf(m, mo);
+    const float L = l * exp2f(m - M) + lo * exp2f(mo - M);
+    if (h == 0) {
+        const long o = (long)split * Bpad + rw * 32 + n;
+        m_part[o] = M;                          // (an empty split leaves M = NEG_BIG, L = 0: weight 0 in the merge)
+        l_part[o] = L;
+        x_part[o] = M;
+    }
+}
+
+// dq[:, col0 : col0 + D] of one slab: sum of the chunks' normalised O partials plus the positive-key term
+//   dq = (sum_j p_j key_j + (p_0 - 1) k) / T ,  p_0 = exp(-loss_row)
+__global__ __launch_bounds__(256) void infonce_slab_dq_kernel(const unsigned* __restrict__ o_part, const float* __restrict__ k,
+                                                              const float* __restrict__ loss_rows, float* __restrict__ dq, int B,
+                                                              int dfull, int col0, int D, float inv_T, int nchunk, int Bpad) {
+    // block = one pair of rows (2m, 2m+1), threads over the slab's columns
+    const int row0 = blockIdx.x * 2;
+    const int qq = row0 & 31, h = (qq >> 2) & 1, r0 = (qq & 3) + 4 * (qq >> 3), j = r0 >> 1;
+    const int nct = D / 32;
+    const long wb_stride = (long)nct * 8 * 64, chunk_stride = (long)(Bpad / 32) * wb_stride;
+    const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + j * 64 + 32 * h;
+    for (int col = threadIdx.x; col < D; col += blockDim.x) {
+        const unsigned* src = base + (long)(col >> 5) * 8 * 64 + (col & 31);
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            const unsigned v = src[(long)c * chunk_stride];
+            a0 += __uint_as_float(v << 16);
+            a1 += __uint_as_float(v & 0xffff0000u);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int b = row0 + u;
+            if (b < B) {
+                const long o = (long)b * dfull + col0 + col;
+                dq[o] = ((u ? a1 : a0) + (expf(-loss_rows[b]) - 1.f) * k[o]) * inv_T;
+            }
+        }
     }
 }
 
@@ -689,17 +845,23 @@ FlashPlan plan(int B, int K) {
 
 }  // namespace
 
+static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
+static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
+
 bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec) {
     if (prec != MOMA_PREC_BF16 || qdtype != MOMA_DT_BF16) return false;
-    if (d != 128 && d != 256 && d != 384 && d != 512) return false;
+    if (!one_pass_dim(d) && !slab_dim(d)) return false;
     return B >= 1 && K >= 1;
 }
 
 size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
-    return rows * d * 2 + 3 * rows * sizeof(float) + ((size_t)p.nchunk * p.nbt * 4 + 4) * sizeof(int) +
-           (size_t)p.Bpad * d * 2 + 1024;
+    const int ds = d > 512 ? 512 : d;                        // widest slab
+    size_t bytes = rows * ds * 2 + 3 * rows * sizeof(float) + ((size_t)p.nchunk * p.nbt * 4 + 4) * sizeof(int) +
+                   (size_t)p.Bpad * ds * 2 + 1024;
+    if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 256;     // score scratch
+    return bytes;
 }
 
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
@@ -707,12 +869,62 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                                 hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
+    const int dsl = d > 512 ? 512 : d;
     float* m_part = (float*)ws;
     float* l_part = m_part + rows;
     float* x_part = l_part + rows;
     int* flags = (int*)(x_part + rows);
     unsigned* o_part = (unsigned*)(((uintptr_t)(flags + (size_t)p.nchunk * p.nbt * 4 + 4) + 255) & ~(uintptr_t)255);
-    uint4* qpack = (uint4*)(((uintptr_t)(o_part + rows * (d / 2)) + 255) & ~(uintptr_t)255);
+    uint4* qpack = (uint4*)(((uintptr_t)(o_part + rows * (dsl / 2)) + 255) & ~(uintptr_t)255);
+    if (d > 512) {
+        // ---- wide queue: column slabs.  scores -> scratch (one launch per slab), statistics, lse / loss / top-1, then
+        //      per slab P.K and the slab's columns of dq
+        float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * dsl * 2) + 255) & ~(uintptr_t)255);
+        const int ntiles = (K + KT - 1) / KT;
+        const float scale_log2s = inv_T * 1.4426950408889634f;
+        const bf16_raw* qu0 = (const bf16_raw*)queue;
+        static bool slab_attr = false;
+        if (!slab_attr) {
+#define MOMA_SLAB_LDS(DD) (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * KT * 512 * 2); \
+                          (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * KT * 512 * 2)
+            MOMA_SLAB_LDS(512); MOMA_SLAB_LDS(384); MOMA_SLAB_LDS(256); MOMA_SLAB_LDS(128);
+#undef MOMA_SLAB_LDS
+            slab_attr = true;
+        }
+        const dim3 sgrid(p.nbt * p.nchunk), sblock(256);
+        auto slab_width = [&](int col0) { const int rem = d - col0; return rem >= 512 ? 512 : rem; };   // 512.., then 384/256/128
+        if (ev_begin) (void)hipEventRecord(ev_begin, st);
+        for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
+            const int D = slab_width(col0);
+            const SlabArgs sa{xs, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
+            const size_t slds = (size_t)NBUF * KT * D * 2;
+#define MOMA_SLAB_SCORES(DD)                                                                                             \
+            do {                                                                                                         \
+                hipLaunchKernelGGL((infonce_qpack_slab_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2s, qpack, p.Bpad / 32); \
+                hipLaunchKernelGGL((infonce_slab_kernel<DD, 1>), sgrid, sblock, slds, st, qpack, qu0 + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa); \
+            } while (0)
+            if (D == 512) MOMA_SLAB_SCORES(512); else if (D == 384) MOMA_SLAB_SCORES(384); else if (D == 256) MOMA_SLAB_SCORES(256); else MOMA_SLAB_SCORES(128);
+#undef MOMA_SLAB_SCORES
+        }
+        if (ev_end) (void)hipEventRecord(ev_end, st);
+        hipLaunchKernelGGL(infonce_slab_stats_kernel, dim3(((p.Bpad / 32) * p.nchunk + 3) / 4), dim3(256), 0, st, xs, K, ntiles,
+                           p.Bpad, p.nchunk, m_part, l_part, x_part);
+        hipLaunchKernelGGL(infonce_combine_kernel, dim3((B + 1) / 2), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
+                           m_part, l_part, x_part, loss_rows, lse, top1, (float*)nullptr);
+        if (dq) {
+            for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
+                const int D = slab_width(col0);
+                const SlabArgs sa{xs, lse, (unsigned)(d * 2), 0};
+                const size_t slds = (size_t)NBUF * KT * D * 2;
+#define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), sgrid, sblock, slds, st, qpack, qu0 + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa)
+                if (D == 512) MOMA_SLAB_PV(512); else if (D == 384) MOMA_SLAB_PV(384); else if (D == 256) MOMA_SLAB_PV(256); else MOMA_SLAB_PV(128);
+#undef MOMA_SLAB_PV
+                hipLaunchKernelGGL(infonce_slab_dq_kernel, dim3((B + 1) / 2), dim3(256), 0, st, o_part, k, loss_rows, dq, B, d, col0, D,
+                                   inv_T, p.nchunk, p.Bpad);
+            }
+        }
+        return hipGetLastError();
+    }
     const float scale_log2 = inv_T * 1.4426950408889634f;
     const dim3 grid(p.nbt * p.nchunk), block(256);
     const dim3 rgrid(min(p.nbt * p.nchunk, 16));     // repair pass: a handful of workgroups walk the (normally empty) list

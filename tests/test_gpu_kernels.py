@@ -138,7 +138,10 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
                                        (16, 1280, 2048, "fp32"), (1, 64, 100, "fp32"),
                                        # bf16 queue + bf16 MFMA -> the one-pass flash kernel (ragged B, K tails)
                                        (100, 384, 5000, "bf16"), (300, 256, 777, "bf16"), (7, 512, 33, "bf16"),
-                                       (129, 512, 65536, "bf16"), (200, 128, 16384, "bf16"), (9, 128, 65, "bf16")])
+                                       (129, 512, 65536, "bf16"), (200, 128, 16384, "bf16"), (9, 128, 65, "bf16"),
+                                       # d > 512: column slabs over a score scratch (512 + 512 + 256, 512 + 128, 4 x 512, 512 + 384)
+                                       (64, 1280, 4096, "bf16"), (33, 640, 1000, "bf16"), (40, 2048, 777, "bf16"),
+                                       (130, 896, 2100, "bf16")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
@@ -170,7 +173,8 @@ def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=(2e-5 if prec == "fp32" else 2e-2) * scale)
 
 
-@pytest.mark.parametrize("B,d,K", [(256, 512, 4096), (100, 384, 1000), (33, 256, 300), (128, 512, 65536), (70, 128, 2000)])
+@pytest.mark.parametrize("B,d,K", [(256, 512, 4096), (100, 384, 1000), (33, 256, 300), (128, 512, 65536), (70, 128, 2000), (50, 1280, 1500),
+                                   (160, 768, 3000)])
 def test_infonce_flash_queue_term(ops, B, d, K):
     """The sum_j p_bj * queue_j part of dq in isolation: k = 0 removes the positive-key term, and every query is
     aligned with a few queue rows so the softmax is peaked and the weighted key sum is O(1), not averaged away."""
