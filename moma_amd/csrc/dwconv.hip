@@ -189,6 +189,59 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_fwd_kernel(const T* __restri
     }
 }
 
+// ---- small planes (OH = OW = 7 or 14): one output ROW per lane ------------------------------------------
+// With 49 / 196 outputs per plane the strip mapping above leaves lanes idle and spends most of its instructions on
+// LDS reads and index arithmetic (0.5 - 1.2 TB/s).  Here a work item is PB whole planes (PB * OWT <= 64), lane =
+// (plane, output row): it reads its K input rows ((OWT-1)*S + K values each) from the tile once, keeps them in
+// registers together with the K*K taps of its plane, and produces the OWT outputs of the row fully unrolled:
+// (K*((OWT-1)*S+K) + K*K) LDS reads and OWT*K*K FMAs per OWT outputs (K=5, OWT=14: 8.2 reads per output instead of 15).
+template <typename T, int K, int S, int OWT, bool FLIP, int VEC>
+__global__ __launch_bounds__(DW_WAVES * 64) void dw_small_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               T* __restrict__ y, DwShape sh) {
+    extern __shared__ float smem[];
+    constexpr int IW = (OWT - 1) * S + K;        // input columns one output row needs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tfl = sh.PB * sh.IR * sh.pitch;
+    float* tile = smem + wave * (tfl + ((sh.PB * K * K + 3) & ~3));
+    float* wl = tile + tfl;
+    for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;          // padding rows / columns stay zero for good
+    const int p = lane / OWT, oy = lane - p * OWT;               // this lane's plane (of the item) and output row
+    const int cbase = XO - sh.pl;
+    for (int item = uniform(blockIdx.x * DW_WAVES + wave); item < sh.ngroups; item += gridDim.x * DW_WAVES) {
+        const int plane0 = item * sh.PB, np = min(sh.PB, sh.NC - plane0);
+        for (int i = lane; i < np * K * K; i += 64) {
+            const int pp = i / (K * K), t = i - pp * (K * K);
+            wl[i] = w[((plane0 + pp) % sh.C) * K * K + (FLIP ? K * K - 1 - t : t)];
+        }
+        fill_tile<T, VEC>(tile, x + (size_t)plane0 * sh.H * sh.W, (size_t)sh.H * sh.W, np, sh.H, sh.W, -sh.pt, sh.IR, sh.pitch,
+                          XO, lane, false);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (p < np) {
+            float wk[K * K];
+#pragma unroll
+            for (int t = 0; t < K * K; ++t) wk[t] = wl[p * K * K + t];
+            float acc[OWT];
+#pragma unroll
+            for (int ox = 0; ox < OWT; ++ox) acc[ox] = 0.f;
+            const float* rowp = tile + (p * sh.IR + oy * S) * sh.pitch + cbase;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                float xr[IW];
+#pragma unroll
+                for (int c = 0; c < IW; ++c) xr[c] = rowp[ky * sh.pitch + c];
+#pragma unroll
+                for (int ox = 0; ox < OWT; ++ox)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) acc[ox] = fmaf(wk[ky * K + kx], xr[ox * S + kx], acc[ox]);
+            }
+            T* o = y + ((size_t)(plane0 + p) * OWT + oy) * OWT;
+#pragma unroll
+            for (int ox = 0; ox < OWT; ++ox) st<T>(o + ox, acc[ox]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
 // ---- backward-data, stride 2 ------------------------------------------------------------------------
 // padded coordinates u = iy + pt, v = ix + pl;  dx[u = 2a+e, v = 2b+f] = sum_{t,s} w[e+2t, f+2s] * dy[a-t, b-s]
 // here sh.H/W = the dy plane (source), sh.OH/OW = the dx plane (result); a band = sh.TH block rows `a`
@@ -373,6 +426,26 @@ hipError_t fwd_t(const T* x, const float* w, T* y, int NC, int C, int H, int W, 
     DwShape sh{};
     sh.NC = NC; sh.C = C; sh.H = H; sh.W = W; sh.OH = OH; sh.OW = OW; sh.pt = pt; sh.pl = pl;
     sh.pitch = round4(XO + max(W, (OW - 1) * S + K - pl) + 1);
+    if (S == 1 && OH == OW && (OW == 7 || OW == 14)) {
+        // small planes: one output row per lane, whole planes per item (stride 2 measured faster on the strip kernel)
+        sh.TH = OH; sh.nbands = 1;
+        sh.IR = (OH - 1) * S + K;
+        sh.PB = OW == 7 ? 8 : 4;
+        sh.pitch |= 1;           // lanes read rows one pitch apart: an odd pitch spreads them over all LDS banks
+        sh.ngroups = (NC + sh.PB - 1) / sh.PB;
+        const size_t lds = (size_t)DW_WAVES * (sh.PB * sh.IR * sh.pitch + round4(sh.PB * K * K)) * sizeof(float);
+        if (lds <= (size_t)LDS_BUDGET) {
+            const dim3 grid(grid_for(sh.ngroups)), block(DW_WAVES * 64);
+            const int vec = 1;       // (odd pitch: element stores into the tile)
+#define MOMA_DW_SMALL(OWT, FL) hipLaunchKernelGGL((dw_small_kernel<T, K, S, OWT, FL, V>), grid, block, lds, st, x, w, y, sh)
+            MOMA_DW_VEC_SWITCH(vec, MAXV, {
+                if (OW == 7) { if (flip) MOMA_DW_SMALL(7, true); else MOMA_DW_SMALL(7, false); }
+                else { if (flip) MOMA_DW_SMALL(14, true); else MOMA_DW_SMALL(14, false); }
+            })
+#undef MOMA_DW_SMALL
+            return hipGetLastError();
+        }
+    }
     const int R = strip_rows(OH);
     sh.TH = pick_th(OH, S, K, sh.pitch, 0, R);
     sh.nbands = (OH + sh.TH - 1) / sh.TH;

@@ -480,7 +480,10 @@ def test_bn_act_matches_torch(ops, shape, dtype, act, training):
 @pytest.mark.parametrize("N,C,H,W,K,S", [(4, 8, 112, 112, 3, 1), (2, 6, 112, 112, 3, 2), (3, 5, 56, 56, 5, 2),
                                          (2, 16, 28, 28, 5, 1), (2, 7, 14, 14, 3, 1), (3, 9, 14, 14, 5, 2),
                                          (2, 11, 7, 7, 5, 1), (2, 3, 9, 13, 3, 2), (1, 2, 33, 17, 5, 1),
-                                         (3, 4, 30, 21, 5, 2), (64, 32, 28, 28, 5, 1), (96, 4, 57, 57, 3, 2)])
+                                         (3, 4, 30, 21, 5, 2), (64, 32, 28, 28, 5, 1), (96, 4, 57, 57, 3, 2),
+                                         # small planes (7 x 7 / 14 x 14 outputs): one output row per lane, ragged plane groups
+                                         (5, 13, 14, 14, 5, 1), (3, 21, 7, 7, 3, 1), (2, 6, 28, 28, 3, 2), (7, 5, 14, 14, 3, 2),
+                                         (33, 3, 7, 7, 5, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_dwconv_matches_torch(ops, N, C, H, W, K, S, dtype):
     """Depthwise conv (dwconv.hip) with TF-SAME padding (asymmetric when the total is odd) against torch conv2d in
