@@ -146,17 +146,20 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
  *     (gamma, beta, running_* may be NULL when training).  act: MOMA_ACT_*.  The backward recomputes the
  *     pre-activation from x and save_mean/save_invstd (written by the forward, eval mode included).
  *     workspace >= moma_bn_workspace_bytes(C) for either call.
+ *     plane_mean (nullable, [N*C], activation dtype): the forward also emits mean_hw(out[n,c]) -- the squeeze of
+ *     a squeeze-excite block that follows (replaces a separate F.adaptive_avg_pool2d pass); dplane_mean (nullable)
+ *     is its gradient, folded into the backward as dout + dplane_mean / HW.
  * ------------------------------------------------------------------------------------------- */
 enum { MOMA_ACT_NONE = 0, MOMA_ACT_SILU = 1, MOMA_ACT_RELU = 2 };
 size_t moma_bn_workspace_bytes(int C);
 int moma_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float* save_mean, float* save_invstd, void* workspace,
                 size_t workspace_bytes, int N, int C, int HW, int dtype, int act, int training,
-                float momentum, float eps, moma_stream_t stream);
+                float momentum, float eps, void* plane_mean, moma_stream_t stream);
 int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta,
                 const float* save_mean, const float* save_invstd, void* dx, float* dgamma, float* dbeta,
                 void* workspace, size_t workspace_bytes, int N, int C, int HW, int dtype, int act,
-                int training, moma_stream_t stream);
+                int training, const void* dplane_mean, moma_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DW  depthwise convolution (groups == channels) on NCHW activations -- the MBConv `_depthwise_conv`

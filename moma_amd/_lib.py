@@ -44,8 +44,8 @@ SIGNATURES = {
     "moma_se_gate_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "moma_se_gate_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "moma_bn_workspace_bytes": (_z, [_i]),
-    "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
-    "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
+    "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
+    "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p, _p]),
     "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i]),
     "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
 }

@@ -118,20 +118,22 @@ class BatchNorm2d(nn.BatchNorm2d):
         self._nbt_pending = 0
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, act=None):
+    def forward(self, x, act=None, want_mean=False):
+        """want_mean: also return the per-plane mean [N,C,1,1] of the result (fused into the apply pass on the GPU)."""
         if _BN_MODE == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.momentum is not None:
             from .. import ops
             use_batch = self.training or self.running_mean is None
             if self.training and self.track_running_stats and self.num_batches_tracked is not None:
                 self._nbt_pending += 1
             return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, use_batch,
-                              self.momentum, self.eps, act)
+                              self.momentum, self.eps, act, want_mean)
         if _BN_MODE == "aten" and x.is_cuda:
             with torch.backends.cudnn.flags(enabled=False):
                 y = super().forward(x)
         else:
             y = super().forward(x)
-        return F.silu(y) if act == "silu" else (F.relu(y) if act == "relu" else y)
+        y = F.silu(y) if act == "silu" else (F.relu(y) if act == "relu" else y)
+        return (y, F.adaptive_avg_pool2d(y, 1)) if want_mean else y
 
 
 def _drop_connect(x, p, training):
@@ -162,14 +164,12 @@ class MBConvBlock(nn.Module):
         inp = x
         if self.expand != 1:
             x = self._bn0(self._expand_conv(x), act="silu")
-        x = self._bn1(self._depthwise_conv(x), act="silu")
+        x, pooled = self._bn1(self._depthwise_conv(x), act="silu", want_mean=True)      # squeeze fused into the BN pass
+        s = self._se_expand(F.silu(self._se_reduce(pooled)))
         if _SE_MODE == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
             from .. import ops
-            s = self._se_expand(F.silu(self._se_reduce(ops.plane_mean(x))))
             x = ops.se_gate(x, s)
         else:
-            s = F.adaptive_avg_pool2d(x, 1)
-            s = self._se_expand(F.silu(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
         x = self._bn2(self._project_conv(x))
         if self.stride == 1 and self.cin == self.cout:

@@ -269,25 +269,25 @@ static int bn_check(int N, int C, int HW, int dtype, int act, const void* ws, si
 
 int moma_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
-                int N, int C, int HW, int dtype, int act, int training, float momentum, float eps,
+                int N, int C, int HW, int dtype, int act, int training, float momentum, float eps, void* plane_mean,
                 moma_stream_t stream) {
     if (!x || !out) return MOMA_E_NULL;
     if (!training && (!running_mean || !running_var)) return MOMA_E_NULL;
     const int rc = bn_check(N, C, HW, dtype, act, workspace, workspace_bytes);
     if (rc != MOMA_OK) return rc;
     return hip_rc(launch_bn_fwd(x, out, gamma, beta, running_mean, running_var, save_mean, save_invstd,
-                                (float*)workspace, N, C, HW, dtype, act, training, momentum, eps, (hipStream_t)stream));
+                                (float*)workspace, N, C, HW, dtype, act, training, momentum, eps, plane_mean, (hipStream_t)stream));
 }
 
 int moma_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* save_mean,
                 const float* save_invstd, void* dx, float* dgamma, float* dbeta, void* workspace,
                 size_t workspace_bytes, int N, int C, int HW, int dtype, int act, int training,
-                moma_stream_t stream) {
+                const void* dplane_mean, moma_stream_t stream) {
     if (!x || !dout || !save_mean || !save_invstd) return MOMA_E_NULL;
     const int rc = bn_check(N, C, HW, dtype, act, workspace, workspace_bytes);
     if (rc != MOMA_OK) return rc;
     return hip_rc(launch_bn_bwd(x, dout, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, (float*)workspace, N,
-                                C, HW, dtype, act, training, (hipStream_t)stream));
+                                C, HW, dtype, act, training, dplane_mean, (hipStream_t)stream));
 }
 
 size_t moma_dwconv_workspace_bytes(int C, int K) {

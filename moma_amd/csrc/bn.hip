@@ -215,7 +215,42 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
     }
 }
 
+// same, one wave per (image, channel) plane, also emitting the plane's mean of the OUTPUT (the squeeze of the
+// squeeze-excite block that follows BN1 + SiLU in an MBConv block: saves a separate read pass over the activation)
+template <typename T, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_mean_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                                   T* __restrict__ pmean,
+                                                                   const float* __restrict__ scale_shift, int NC, int C,
+                                                                   int HW, int act) {
+    const int lane = threadIdx.x & 63;
+    const int nv = HW / VEC;
+    for (int plane = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6); plane < NC; plane += gridDim.x * (BN_THREADS / 64)) {
+        const int c = plane % C;
+        const float sc = scale_shift[2 * c], sh = scale_shift[2 * c + 1];
+        const T* p = x + (size_t)plane * HW;
+        T* o = out + (size_t)plane * HW;
+        float acc = 0.f;
+        for (int i = lane; i < nv; i += 64) {
+            float v[VEC];
+            VecIO<T, VEC>::load(p + (size_t)i * VEC, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                v[j] = act_fwd(fmaf(v[j], sc, sh), act);
+                acc += v[j];
+            }
+            VecIO<T, VEC>::store(o + (size_t)i * VEC, v);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float m[1] = {acc / (float)HW};
+            VecIO<T, 1>::store(pmean + plane, m);
+        }
+    }
+}
+
 // ---- backward reductions: partial[(c*S + s)*2 ..] = (sum dy, sum dy*xhat), dy = dout * act'(y) --------
+// `dpl` (nullable): gradient of the plane means emitted by bn_apply_mean_kernel; every element of plane p then carries
+// dout + dpl[p] / HW  (what autograd would otherwise materialise and add in two more passes)
 template <typename T, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dout,
                                                                    const float* __restrict__ gamma,
@@ -223,11 +258,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
                                                                    const float* __restrict__ save_mean,
                                                                    const float* __restrict__ save_invstd,
                                                                    float* __restrict__ partial, int N, int C, int HW,
-                                                                   int act) {
+                                                                   int act, const T* __restrict__ dpl) {
     const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
     const unsigned hwv = HW / VEC, total = (unsigned)N * hwv;
     const float mean = save_mean[c], invstd = save_invstd[c];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float inv_hw = 1.f / (float)HW;
     float s1 = 0.f, s2 = 0.f;
     for (unsigned i = s * BN_THREADS + threadIdx.x; i < total; i += S * BN_THREADS) {
         const unsigned n = i / hwv, r = i - n * hwv;
@@ -235,10 +271,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
         float xv[VEC], dv[VEC];
         VecIO<T, VEC>::load(x + off, xv);
         VecIO<T, VEC>::load(dout + off, dv);
+        float add = 0.f;
+        if (dpl) { float t1[1]; VecIO<T, 1>::load(dpl + (size_t)n * C + c, t1); add = t1[0] * inv_hw; }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (xv[j] - mean) * invstd;
-            const float dy = dv[j] * act_grad(fmaf(xh, g, b), act);
+            const float dy = (dv[j] + add) * act_grad(fmaf(xh, g, b), act);
             s1 += dy;
             s2 = fmaf(dy, xh, s2);
         }
@@ -287,8 +325,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
                                                                   const float* __restrict__ save_mean,
                                                                   const float* __restrict__ save_invstd,
                                                                   const float* __restrict__ coef, int C, int HW,
-                                                                  size_t nvec, int act) {
+                                                                  size_t nvec, int act, const T* __restrict__ dpl) {
     const unsigned hwv = HW / VEC;
+    const float inv_hw = 1.f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (size_t)gridDim.x * BN_THREADS) {
         const unsigned plane = (unsigned)(i / hwv), c = plane % (unsigned)C;
         const float mean = save_mean[c], invstd = save_invstd[c];
@@ -297,10 +336,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
         float xv[VEC], dv[VEC];
         VecIO<T, VEC>::load(x + i * VEC, xv);
         VecIO<T, VEC>::load(dout + i * VEC, dv);
+        float add = 0.f;
+        if (dpl) { float t1[1]; VecIO<T, 1>::load(dpl + plane, t1); add = t1[0] * inv_hw; }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (xv[j] - mean) * invstd;
-            const float dy = dv[j] * act_grad(fmaf(xh, g, b), act);
+            const float dy = (dv[j] + add) * act_grad(fmaf(xh, g, b), act);
             xv[j] = a * (dy - b1 - xh * b2);
         }
         VecIO<T, VEC>::store(dx + i * VEC, xv);
@@ -332,7 +373,7 @@ unsigned apply_grid(size_t nvec) {
 template <typename T>
 hipError_t bn_fwd_t(const T* x, T* out, const float* gamma, const float* beta, float* rm, float* rv, float* save_mean,
                     float* save_invstd, float* ws, int N, int C, int HW, int act, int training, float momentum,
-                    float eps, hipStream_t st) {
+                    float eps, T* pmean, hipStream_t st) {
     const int vec = pick_vec(HW, sizeof(T), x, out, nullptr);
     const int S = training ? pick_splits(N, C, HW, vec) : 1;
     float* scale_shift = ws;                   // [C][2]
@@ -346,6 +387,15 @@ hipError_t bn_fwd_t(const T* x, T* out, const float* gamma, const float* beta, f
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, S, gamma, beta, rm, rv,
                        save_mean, save_invstd, scale_shift, C, training, momentum, eps);
+    if (pmean) {
+        long gp = ((long)N * C + BN_THREADS / 64 - 1) / (BN_THREADS / 64);
+        if (gp > 256 * 32) gp = 256 * 32;
+        const dim3 pg((unsigned)gp);
+        if (vec == 8) hipLaunchKernelGGL((bn_apply_mean_kernel<T, 8>), pg, dim3(BN_THREADS), 0, st, x, out, pmean, scale_shift, N * C, C, HW, act);
+        else if (vec == 4) hipLaunchKernelGGL((bn_apply_mean_kernel<T, 4>), pg, dim3(BN_THREADS), 0, st, x, out, pmean, scale_shift, N * C, C, HW, act);
+        else hipLaunchKernelGGL((bn_apply_mean_kernel<T, 1>), pg, dim3(BN_THREADS), 0, st, x, out, pmean, scale_shift, N * C, C, HW, act);
+        return hipGetLastError();
+    }
     const unsigned g = apply_grid(nvec);
     if (vec == 8) hipLaunchKernelGGL((bn_apply_kernel<T, 8>), dim3(g), dim3(BN_THREADS), 0, st, x, out, scale_shift, C, HW, nvec, act);
     else if (vec == 4) hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(g), dim3(BN_THREADS), 0, st, x, out, scale_shift, C, HW, nvec, act);
@@ -356,23 +406,23 @@ hipError_t bn_fwd_t(const T* x, T* out, const float* gamma, const float* beta, f
 template <typename T>
 hipError_t bn_bwd_t(const T* x, const T* dout, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, T* dx, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
-                    int act, int training, hipStream_t st) {
+                    int act, int training, const T* dpl, hipStream_t st) {
     const int vec = pick_vec(HW, sizeof(T), x, dout, dx);
     const int S = pick_splits(N, C, HW, vec);
     float* coef = ws;                          // [C][3]
     float* partial = ws + 3 * (size_t)C;       // [C][S][2]
     const size_t nvec = (size_t)N * C * HW / vec;
     dim3 grid(S, C);
-    if (vec == 8) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
-    else if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act);
+    if (vec == 8) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 8>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act, dpl);
+    else if (vec == 4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act, dpl);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), grid, dim3(BN_THREADS), 0, st, x, dout, gamma, beta, save_mean, save_invstd, partial, N, C, HW, act, dpl);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, S, gamma, save_invstd,
                        dgamma, dbeta, coef, C, (float)N * (float)HW, training);
     if (dx) {
         const unsigned g = apply_grid(nvec);
-        if (vec == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act);
-        else if (vec == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act);
-        else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act);
+        if (vec == 8) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act, dpl);
+        else if (vec == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act, dpl);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(g), dim3(BN_THREADS), 0, st, x, dout, dx, gamma, beta, save_mean, save_invstd, coef, C, HW, nvec, act, dpl);
     }
     return hipGetLastError();
 }
@@ -382,21 +432,21 @@ size_t bn_workspace_floats(int C) { return (size_t)C * (3 + 64 * 3); }
 
 hipError_t launch_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* rm, float* rv,
                          float* save_mean, float* save_invstd, float* ws, int N, int C, int HW, int dtype, int act,
-                         int training, float momentum, float eps, hipStream_t st) {
+                         int training, float momentum, float eps, void* plane_mean, hipStream_t st) {
     if (dtype == MOMA_DT_BF16)
         return bn_fwd_t<bf16_raw>((const bf16_raw*)x, (bf16_raw*)out, gamma, beta, rm, rv, save_mean, save_invstd, ws, N,
-                                  C, HW, act, training, momentum, eps, st);
+                                  C, HW, act, training, momentum, eps, (bf16_raw*)plane_mean, st);
     return bn_fwd_t<float>((const float*)x, (float*)out, gamma, beta, rm, rv, save_mean, save_invstd, ws, N, C, HW, act,
-                           training, momentum, eps, st);
+                           training, momentum, eps, (float*)plane_mean, st);
 }
 hipError_t launch_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, void* dx, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
-                         int dtype, int act, int training, hipStream_t st) {
+                         int dtype, int act, int training, const void* dplane_mean, hipStream_t st) {
     if (dtype == MOMA_DT_BF16)
         return bn_bwd_t<bf16_raw>((const bf16_raw*)x, (const bf16_raw*)dout, gamma, beta, save_mean, save_invstd,
-                                  (bf16_raw*)dx, dgamma, dbeta, ws, N, C, HW, act, training, st);
+                                  (bf16_raw*)dx, dgamma, dbeta, ws, N, C, HW, act, training, (const bf16_raw*)dplane_mean, st);
     return bn_bwd_t<float>((const float*)x, (const float*)dout, gamma, beta, save_mean, save_invstd, (float*)dx, dgamma,
-                           dbeta, ws, N, C, HW, act, training, st);
+                           dbeta, ws, N, C, HW, act, training, (const float*)dplane_mean, st);
 }
 
 }  // namespace moma

@@ -88,10 +88,10 @@ hipError_t launch_mha_core_bwd(const float* qkv, const float* probs, const float
 size_t bn_workspace_floats(int C);
 hipError_t launch_bn_fwd(const void* x, void* out, const float* gamma, const float* beta, float* rm, float* rv,
                          float* save_mean, float* save_invstd, float* ws, int N, int C, int HW, int dtype, int act,
-                         int training, float momentum, float eps, hipStream_t st);
+                         int training, float momentum, float eps, void* plane_mean, hipStream_t st);
 hipError_t launch_bn_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* save_mean,
                          const float* save_invstd, void* dx, float* dgamma, float* dbeta, float* ws, int N, int C, int HW,
-                         int dtype, int act, int training, hipStream_t st);
+                         int dtype, int act, int training, const void* dplane_mean, hipStream_t st);
 
 // ---- dwconv.hip (depthwise convolution, NCHW) -----------------------------------------------------
 bool dwconv_supported(int K, int S);

@@ -317,7 +317,7 @@ _DT_CODES = {torch.float32: 0, torch.bfloat16: 1}
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, want_mean):
         lib = _lib.load()
         _dev(x, "x", dtype=None, contiguous=False)
         if x.dim() < 2 or x.dtype not in _DT_CODES:
@@ -330,21 +330,27 @@ class _BNAct(torch.autograd.Function):
         save_mean = torch.empty(Cc, device=dev, dtype=torch.float32)
         save_invstd = torch.empty(Cc, device=dev, dtype=torch.float32)
         ws = torch.empty(lib.moma_bn_workspace_bytes(Cc), device=dev, dtype=torch.uint8)
+        pmean = torch.empty(N, Cc, 1, 1, device=dev, dtype=x.dtype) if want_mean else None
         check(lib.moma_bn_fwd(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                               _ptr(save_mean), _ptr(save_invstd), _ptr(ws), ws.numel(), N, Cc, HW, _DT_CODES[x.dtype],
-                              act, int(training), float(momentum), float(eps), _stream()), "moma_bn_fwd")
+                              act, int(training), float(momentum), float(eps), _ptr(pmean), _stream()), "moma_bn_fwd")
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.cfg = (N, Cc, HW, act, int(training))
-        return out
+        ctx.set_materialize_grads(False)
+        return (out, pmean) if want_mean else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dmean=None):
         lib = _lib.load()
         x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
         N, Cc, HW, act, training = ctx.cfg
+        if dout is None:
+            dout = torch.zeros_like(x)
         dout = dout.contiguous()
         if dout.dtype != x.dtype:
             dout = dout.to(x.dtype)
+        if dmean is not None:
+            dmean = dmean.to(x.dtype).contiguous()
         dev = x.device
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dgamma = torch.empty(Cc, device=dev, dtype=torch.float32) if (weight is not None and ctx.needs_input_grad[1]) else None
@@ -352,13 +358,16 @@ class _BNAct(torch.autograd.Function):
         ws = torch.empty(lib.moma_bn_workspace_bytes(Cc), device=dev, dtype=torch.uint8)
         check(lib.moma_bn_bwd(_ptr(x), _ptr(dout), _ptr(weight), _ptr(bias), _ptr(save_mean), _ptr(save_invstd), _ptr(dx),
                               _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), N, Cc, HW, _DT_CODES[x.dtype], act,
-                              training, _stream()), "moma_bn_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+                              training, _ptr(dmean), _stream()), "moma_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float, act=None):
-    """act(batch_norm(x)) on a contiguous NCHW tensor; running statistics are updated in place when training."""
-    return _BNAct.apply(x, weight, bias, running_mean, running_var, bool(training), momentum, eps, ACT_CODES[act])
+def bn_act(x, weight, bias, running_mean, running_var, training: bool, momentum: float, eps: float, act=None,
+           want_mean: bool = False):
+    """act(batch_norm(x)) on a contiguous NCHW tensor; running statistics are updated in place when training.
+    want_mean: also return the [N,C,1,1] per-plane mean of the result (the squeeze of a squeeze-excite block)."""
+    return _BNAct.apply(x, weight, bias, running_mean, running_var, bool(training), momentum, eps, ACT_CODES[act],
+                        bool(want_mean))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -561,3 +561,40 @@ def test_se_gate_and_plane_mean_match_torch(ops, shape, dtype):
     rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (1.6e-2, 1.6e-2)
     torch.testing.assert_close(y.double(), ref.detach(), rtol=rtol, atol=atol)
     torch.testing.assert_close(xx.grad.double(), xd.grad, rtol=rtol, atol=atol * max(1.0, xd.grad.abs().max().item()))
+
+
+@pytest.mark.parametrize("shape", [(8, 24, 56, 56), (6, 40, 14, 14), (4, 96, 7, 7), (3, 5, 9, 11)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_with_plane_mean(ops, shape, dtype):
+    """BN + SiLU with the squeeze fused in: the second output is mean_hw of the first, and its gradient is folded into the
+    BN backward (dout + dmean / HW) -- compared with torch on a loss that uses both outputs."""
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + 3)
+    Cc = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).cuda().to(dtype)
+    w = (1.0 + 0.3 * torch.randn(Cc, generator=g)).cuda()
+    b = (0.2 * torch.randn(Cc, generator=g)).cuda()
+    dout = torch.randn(shape, generator=g).cuda().to(dtype)
+    dmean = torch.randn(shape[0], Cc, 1, 1, generator=g).cuda().to(dtype) * 3
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.silu(torch.nn.functional.batch_norm(xd, None, None, wd, bd, True, 0.01, 1e-3))
+    mr = yr.mean((2, 3), keepdim=True)
+    ((yr * dout.double()).sum() + (mr * dmean.double()).sum()).backward()
+    xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y, m = ops.bn_act(xx, ww, bb, None, None, True, 0.01, 1e-3, "silu", want_mean=True)
+    assert m.shape == (shape[0], Cc, 1, 1) and m.dtype == dtype
+    ((y.float() * dout.float()).sum() + (m.float() * dmean.float()).sum()).backward()
+    rtol, atol = (2e-5, 2e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    torch.testing.assert_close(y.double(), yr.detach(), rtol=rtol, atol=atol)
+    torch.testing.assert_close(m.double(), mr.detach(), rtol=rtol, atol=atol)
+    torch.testing.assert_close(xx.grad.double(), xd.grad, rtol=rtol, atol=atol * max(1.0, xd.grad.abs().max().item()))
+    n_el = x.numel() // Cc
+    torch.testing.assert_close(ww.grad.double(), wd.grad, rtol=1e-3, atol=2e-4 * n_el ** 0.5 * (1 if dtype == torch.float32 else 30))
+    torch.testing.assert_close(bb.grad.double(), bd.grad, rtol=1e-3, atol=2e-4 * n_el ** 0.5 * (1 if dtype == torch.float32 else 30))
+    # the mean alone (no gradient for the first output) still back-propagates
+    xx2 = x.clone().requires_grad_(True)
+    _, m2 = ops.bn_act(xx2, w, b, None, None, True, 0.01, 1e-3, "silu", want_mean=True)
+    (m2.float() * dmean.float()).sum().backward()
+    xd2 = x.double().requires_grad_(True)
+    (torch.nn.functional.silu(torch.nn.functional.batch_norm(xd2, None, None, w.double(), b.double(), True, 0.01, 1e-3))
+     .mean((2, 3), keepdim=True) * dmean.double()).sum().backward()
+    torch.testing.assert_close(xx2.grad.double(), xd2.grad, rtol=rtol, atol=atol * max(1.0, xd2.grad.abs().max().item()))
