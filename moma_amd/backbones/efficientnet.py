@@ -67,11 +67,44 @@ class _DepthwiseNative(torch.autograd.Function):
         return gx, (gw.float() if gw is not None else None), None, None, None
 
 
+class _CachedCast(torch.autograd.Function):
+    """Identity-with-cast whose forward returns an up-to-date low-precision copy kept elsewhere (one multi-tensor cast
+    per model forward instead of one tiny cast kernel per parameter); the backward is the ordinary cast back."""
+
+    @staticmethod
+    def forward(ctx, master, cached):
+        ctx.dtype = master.dtype
+        return cached.view_as(cached)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype), None
+
+
+# MOMA_WCACHE=1 (default): under bf16 autocast on the GPU a model forward first refreshes bf16 copies of all its
+# convolution weights / biases with ONE multi-tensor copy (autocast otherwise launches a cast kernel per parameter and
+# forward: ~340 launches of ~4 us per train step) and the convolutions take the copies.
+_WCACHE = os.environ.get("MOMA_WCACHE", "1") == "1"
+
+
 class SamePadConv2d(nn.Conv2d):
     """Conv2d with TensorFlow 'SAME' padding computed from the input size at call time."""
 
     def __init__(self, cin, cout, kernel_size, stride=1, groups=1, bias=True):
         super().__init__(cin, cout, kernel_size, stride=stride, padding=0, groups=groups, bias=bias)
+        self._wc = self._bc = None                  # bf16 copies, valid for the model forward that refreshed them
+        self._wc_live = False
+
+    def _params(self, x):
+        """(weight, bias) for this call: the refreshed bf16 copies when the enclosing model forward provided them."""
+        if self._wc_live and x.is_cuda and x.dtype == torch.bfloat16:
+            track = torch.is_grad_enabled()
+            w = _CachedCast.apply(self.weight, self._wc) if (track and self.weight.requires_grad) else self._wc
+            b = None
+            if self.bias is not None:
+                b = _CachedCast.apply(self.bias, self._bc) if (track and self.bias.requires_grad) else self._bc
+            return w, b
+        return self.weight, self.bias
 
     def forward(self, x):
         ih, iw = x.shape[-2:]
@@ -84,8 +117,9 @@ class SamePadConv2d(nn.Conv2d):
             from .. import ops
             if ops.dwconv_supported(kh, sh):
                 if torch.is_autocast_enabled():
-                    x = x.to(torch.get_autocast_gpu_dtype())
+                    x = x.to(torch.get_autocast_dtype("cuda"))
                 if x.dtype in (torch.float32, torch.bfloat16):
+                    # (the depthwise kernels take the fp32 master weights directly: no cast at all)
                     return ops.dwconv(x, self.weight, sh, ph // 2, pw // 2, math.ceil(ih / sh), math.ceil(iw / sw))
         pad = (ph // 2, pw // 2)
         if ph % 2 or pw % 2:
@@ -93,9 +127,13 @@ class SamePadConv2d(nn.Conv2d):
             pad = 0
         if depthwise and x.is_cuda and _DW_MODE in ("hip", "aten"):
             if torch.is_autocast_enabled():
-                x = x.to(torch.get_autocast_gpu_dtype())
+                x = x.to(torch.get_autocast_dtype("cuda"))
             return _DepthwiseNative.apply(x, self.weight, self.stride, pad, self.groups)
-        return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
+        if self._wc_live and torch.is_autocast_enabled() and x.is_cuda and x.dtype != torch.bfloat16 and \
+                torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        w, b = self._params(x)
+        return F.conv2d(x, w, b, self.stride, pad, self.dilation, self.groups)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -221,11 +259,37 @@ class EfficientNet(nn.Module):
     def get_feat_modules(self):
         return nn.ModuleList([self._conv_stem, self._bn0, self._blocks, self._conv_head, self._bn1, self.classifier_])
 
+    def _refresh_weight_cache(self, x):
+        """One multi-tensor fp32 -> bf16 copy of every non-depthwise conv weight / bias (see _WCACHE)."""
+        live = (_WCACHE and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        convs = getattr(self, "_wcache_convs", None)
+        if convs is None:
+            convs = [m for m in self.modules() if isinstance(m, SamePadConv2d) and not (m.groups > 1 and _DW_MODE == "hip")]
+            object.__setattr__(self, "_wcache_convs", convs)
+        if not live:
+            for m in convs:
+                m._wc_live = False
+            return
+        src, dst = [], []
+        for m in convs:
+            if m._wc is None or m._wc.device != m.weight.device:
+                m._wc = torch.empty_like(m.weight, dtype=torch.bfloat16)
+                m._bc = torch.empty_like(m.bias, dtype=torch.bfloat16) if m.bias is not None else None
+            src.append(m.weight.detach()); dst.append(m._wc)
+            if m.bias is not None:
+                src.append(m.bias.detach()); dst.append(m._bc)
+            m._wc_live = True
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+
     def forward(self, x, is_feat=False):
+        self._refresh_weight_cache(x)
         out = self.extract_endpoints(x)
         pooled = self._avg_pooling(out[-1])
         out.append(pooled)
         logits = self.classifier_(pooled.flatten(start_dim=1))
+        for m in self._wcache_convs:                 # the copies are only valid inside this forward
+            m._wc_live = False
         return (out, logits) if is_feat else logits
 
 

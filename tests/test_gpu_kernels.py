@@ -598,3 +598,39 @@ def test_bn_act_with_plane_mean(ops, shape, dtype):
     (torch.nn.functional.silu(torch.nn.functional.batch_norm(xd2, None, None, w.double(), b.double(), True, 0.01, 1e-3))
      .mean((2, 3), keepdim=True) * dmean.double()).sum().backward()
     torch.testing.assert_close(xx2.grad.double(), xd2.grad, rtol=rtol, atol=atol * max(1.0, xd2.grad.abs().max().item()))
+
+
+def test_effnet_weight_cache_is_transparent():
+    """MOMA_WCACHE: one multi-tensor bf16 copy of the conv weights per model forward instead of autocast's per-parameter
+    cast kernels -- same numbers out, same gradients in the fp32 parameters, copies refreshed after an in-place update."""
+    from moma_amd.backbones import efficientnet as E
+    torch.manual_seed(0)
+    net = E.efficientnet_b0(num_classes=3).cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+
+    def run(cache):
+        old, E._WCACHE = E._WCACHE, cache
+        try:
+            torch.manual_seed(1)                               # same drop-connect masks
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                feats, logits = net(x, is_feat=True)
+            logits.float().square().sum().backward()
+            return logits.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            E._WCACHE = old
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert torch.equal(y0, y1)
+    assert g0.keys() == g1.keys() and all(g1[n].dtype == torch.float32 for n in g1)
+    for n in g0:        # (MIOpen's bf16 weight gradients use split reductions with atomics: not bit-reproducible run to run)
+        err = (g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), 1e-12)
+        assert err < 2e-2, (n, err)
+    with torch.no_grad():
+        net._conv_stem.weight.mul_(2.0)                        # an optimizer step / EMA update changes the masters ...
+    y2, _ = run(True)
+    assert not torch.equal(y1, y2)                             # ... and the next forward sees it
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        net.eval()
+        assert torch.isfinite(net(x)).all()
