@@ -145,7 +145,6 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
-    q = rng.standard_normal((B, d)).astype(np.float32) * 0.7 / np.sqrt(d) * np.sqrt(d) / np.sqrt(d)
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
