@@ -339,7 +339,9 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {a.model} student+teacher (random init), synthetic "
                                    f"{a.image_size}x{a.image_size} RGB, per-GPU batch {a.batch_size}, queue K={a.nce_k} "
                                    f"x d={d} ({a.queue_dtype}), head={a.head}, attn=self (4 heads), -c 1 -d 1 -b 1, "
-                                   f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp}, KD kernels {a.moma_prec}",
+                                   f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp} (BN+SiLU / depthwise / SE on the library's helper "
+                                   f"kernels: MOMA_BN={os.environ.get('MOMA_BN', 'hip')} MOMA_DW={os.environ.get('MOMA_DW', 'hip')} "
+                                   f"MOMA_SE={os.environ.get('MOMA_SE', 'hip')}), KD kernels {a.moma_prec}",
                        "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank"},
             "roofline": roof,
         }
