@@ -304,12 +304,16 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_data_s2_kernel(const T* 
 // ---- backward-weight --------------------------------------------------------------------------------
 // dw[c, ky, kx] = sum_{n, oy, ox} dy[n,c,oy,ox] * x[n,c, oy*S+ky-pt, ox*S+kx-pl];  grid (nsplit/4, C): one wave visits
 // image groups (PB consecutive images of channel c) x bands and keeps K*K accumulators per lane.
-template <typename T, int K, int S, int R, int VEC, int GVEC>
+// GDIRECT: dy goes global -> registers inside the strip loop instead of through a second LDS tile (each dy value is used
+// by one lane only).  Without the dy tile the x tile can be twice as tall at the same occupancy, which wins where the
+// halo is large (K = 5) or the planes are small; on the K = 3 layers with 56^2 / 112^2 planes the loads' latency in the
+// inner loop costs more than the shorter bands (measured both ways, scripts/bench_dw.py).
+template <typename T, int K, int S, int R, int VEC, int GVEC, bool GDIRECT>
 __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     float* __restrict__ partial, DwShape sh, int N) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int xt = sh.PB * sh.IR * sh.pitch, gtn = sh.PB * sh.GR * sh.gpitch;
+    const int xt = sh.PB * sh.IR * sh.pitch, gtn = GDIRECT ? 0 : sh.PB * sh.GR * sh.gpitch;
     float* tile = smem + wave * (xt + gtn);
     float* gt = tile + xt;
     for (int i = lane; i < xt + gtn; i += 64) tile[i] = 0.f;
@@ -330,19 +334,35 @@ __global__ __launch_bounds__(DW_WAVES * 64) void dw_bwd_weight_kernel(const T* _
         fill_tile<T, VEC>(tile, x + ((size_t)n0 * sh.C + c) * sh.H * sh.W, xs, np, sh.H, sh.W, oy0 * S - sh.pt, sh.IR, sh.pitch, XO,
                           lane, sh.nbands > 1);
         // dy rows of the band; rows past the plane's end are zero, so that a short last band contributes nothing
-        fill_tile<T, GVEC>(gt, dy + ((size_t)n0 * sh.C + c) * sh.OH * sh.OW, gs, np, sh.OH, sh.OW, oy0, sh.GR, sh.gpitch, 0, lane,
-                           sh.nbands > 1);
+        if constexpr (!GDIRECT)
+            fill_tile<T, GVEC>(gt, dy + ((size_t)n0 * sh.C + c) * sh.OH * sh.OW, gs, np, sh.OH, sh.OW, oy0, sh.GR, sh.gpitch, 0,
+                               lane, sh.nbands > 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         const int nwork = nstrips * sh.OW;
         const float inv_ow = 1.0f / (float)sh.OW;
         for (int p = 0; p < np; ++p) {
             const float* pt_ = tile + p * sh.IR * sh.pitch + cbase;
             const float* gp = gt + p * sh.GR * sh.gpitch;
+            const T* gd = dy + ((size_t)(n0 + p) * sh.C + c) * sh.OH * sh.OW;
             for (int i = lane; i < nwork; i += 64) {
                 const int strip = fast_div(i, sh.OW, inv_ow), ox = i - strip * sh.OW;
                 float g[R];
+                if constexpr (GDIRECT) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) g[r] = gp[(strip * R + r) * sh.gpitch + ox];
+                    for (int r = 0; r < R; ++r) {
+                        float t1[1];
+                        Vec<T, 1>::ld(gd + (size_t)min(oy0 + strip * R + r, sh.OH - 1) * sh.OW + ox, t1);
+                        g[r] = t1[0];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        asm volatile("" : "+v"(g[r]));         // keep the loads unconditional and together
+                        g[r] = (oy0 + strip * R + r < sh.OH) ? g[r] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) g[r] = gp[(strip * R + r) * sh.gpitch + ox];
+                }
                 const float* base = pt_ + (strip * R * S) * sh.pitch + ox * S;
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
@@ -498,12 +518,13 @@ hipError_t bwd_weight_t(const T* x, const T* dy, float* dw, float* ws, size_t ws
     DwShape sh{};
     sh.NC = N * C; sh.C = C; sh.H = H; sh.W = W; sh.OH = OH; sh.OW = OW; sh.pt = pt; sh.pl = pl;
     sh.pitch = round4(XO + max(W, (OW - 1) * S + K - pl) + 1);
-    sh.gpitch = round4(OW);
+    const bool gdirect = !(K == 3 && OH >= 56);
+    sh.gpitch = gdirect ? 0 : round4(OW + 1);
     const int R = strip_rows(OH);
     sh.TH = pick_th(OH, S, K, sh.pitch, sh.gpitch, R);
     sh.nbands = (OH + sh.TH - 1) / sh.TH;
     sh.IR = (sh.TH - 1) * S + K;
-    sh.GR = sh.TH;
+    sh.GR = gdirect ? 0 : sh.TH;
     sh.PB = fit_planes(min(planes_per_item(OH, OW, sh.nbands), N), (long)sh.IR * sh.pitch + (long)sh.GR * sh.gpitch);
     sh.ngroups = (N + sh.PB - 1) / sh.PB;          // groups of images (per channel)
     const size_t lds = (size_t)DW_WAVES * sh.PB * (sh.IR * sh.pitch + sh.GR * sh.gpitch) * sizeof(float);
@@ -515,10 +536,11 @@ hipError_t bwd_weight_t(const T* x, const T* dy, float* dw, float* ws, size_t ws
     const dim3 grid((unsigned)nsplit_wg, C), block(DW_WAVES * 64);
     const int vec = pick_vec(W, sizeof(T), x), gvec = pick_vec(OW, sizeof(T), dy);
     // (the dy tile takes the x tile's vector width when that divides OW too, else scalar: keeps the instantiations down)
-#define MOMA_DW_GO(RR, GV) hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S, RR, V, GV>), grid, block, lds, st, x, dy, ws, sh, N)
+#define MOMA_DW_GO(RR, GV, GD) hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S, RR, V, GV, GD>), grid, block, lds, st, x, dy, ws, sh, N)
     MOMA_DW_VEC_SWITCH(vec, MAXV, {
-        if (gvec >= V) { if (R == 4) MOMA_DW_GO(4, V); else if (R == 2) MOMA_DW_GO(2, V); else MOMA_DW_GO(1, V); }
-        else { if (R == 4) MOMA_DW_GO(4, 1); else if (R == 2) MOMA_DW_GO(2, 1); else MOMA_DW_GO(1, 1); }
+        if (gdirect) { if (R == 4) MOMA_DW_GO(4, 1, true); else if (R == 2) MOMA_DW_GO(2, 1, true); else MOMA_DW_GO(1, 1, true); }
+        else if (gvec >= V) { if (R == 4) MOMA_DW_GO(4, V, false); else if (R == 2) MOMA_DW_GO(2, V, false); else MOMA_DW_GO(1, V, false); }
+        else { if (R == 4) MOMA_DW_GO(4, 1, false); else if (R == 2) MOMA_DW_GO(2, 1, false); else MOMA_DW_GO(1, 1, false); }
     })
 #undef MOMA_DW_GO
     const int total = C * K * K;
