@@ -1,0 +1,81 @@
+"""HIP-graph replay of a no-grad module forward (the two teacher forwards of a MoMA step).
+
+The train step launches ~2400 kernels; on the host that is ~35 ms of Python / ATen / MIOpen dispatch per step, two
+thirds of the forward part of it in the two teacher passes (reference helper/loops_moma.py:270-272 and
+learning/contrast_trainer.py:118-121), which are inference-only: fixed shapes, no autograd, weights updated in place by the
+EMA kernel.  `GraphedInference` runs such a forward eagerly a few times (MIOpen compiles / selects its kernels), then
+captures it once per (input shape, dtype, autocast state, train/eval flags) into a `torch.cuda.CUDAGraph` (= hipGraph) and
+replays it: one launch instead of ~700.  Parameters and buffers are read and written through their own storage, so EMA
+updates and BatchNorm running statistics behave exactly as in eager mode; dropout-like ops draw from the graph-safe
+Philox stream.  Anything unusual (CPU tensors, grad mode on, a capture error) falls back to the eager call.
+"""
+import os
+
+import torch
+
+
+class GraphedInference:
+    def __init__(self, module, warmup: int = 3):
+        self.module = module
+        self.warmup = warmup
+        self.enabled = os.environ.get("MOMA_GRAPH_TEACHER", "1") == "1"
+        self._seen = {}
+        self._graphs = {}
+        self._mods = list(module.modules())
+
+    # the wrapped module stays reachable for everything that is not a forward call
+    def __getattr__(self, name):
+        return getattr(self.__dict__["module"], name)
+
+    def _key(self, x, is_feat):
+        ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
+        modes = hash(tuple(m.training for m in self._mods))
+        return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes)
+
+    def __call__(self, x, is_feat=False):
+        if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
+            return self.module(x, is_feat=is_feat)
+        key = self._key(x, is_feat)
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._seen.get(key, 0) + 1
+            self._seen[key] = n
+            if n <= self.warmup:
+                return self.module(x, is_feat=is_feat)
+            entry = self._capture(key, x, is_feat)
+            if entry is None:
+                return self.module(x, is_feat=is_feat)
+        graph, static_x, out, bn_train = entry
+        static_x.copy_(x)
+        graph.replay()
+        for m in bn_train:                                    # host-side batch counters (see backbones' BatchNorm2d)
+            m._nbt_pending += 1
+        return self._detach_outputs(out, is_feat)
+
+    def _capture(self, key, x, is_feat):
+        try:
+            static_x = x.clone()
+            graph = torch.cuda.CUDAGraph()
+            pending = [(m, m._nbt_pending) for m in self._mods if hasattr(m, "_nbt_pending")]
+            with torch.cuda.graph(graph):
+                out = self.module(static_x, is_feat=is_feat)
+            # the capture ran the Python side once without executing kernels: undo its host-side counting
+            bn_train = [m for m, before in pending if m._nbt_pending != before]
+            for m, before in pending:
+                m._nbt_pending = before
+            entry = (graph, static_x, out, bn_train)
+            self._graphs[key] = entry
+            return entry
+        except Exception as e:                                 # pragma: no cover - depends on the runtime
+            print(f"[moma] HIP-graph capture of the teacher forward failed ({type(e).__name__}: {e}); staying eager")
+            self.enabled = False
+            return None
+
+    @staticmethod
+    def _detach_outputs(out, is_feat):
+        """Static graph outputs are overwritten by the next replay: the small tensors callers keep across it (pooled
+        feature, logits) are cloned, the large intermediate features are handed out as they are."""
+        if is_feat:
+            feats, logits = out
+            return list(feats[:-1]) + [feats[-1].clone()], logits.clone()
+        return out.clone()

@@ -56,6 +56,14 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             if torch.cuda.is_available() else torch.device("cpu")
     ema_ok = None
     kd_params = None
+    # the teacher's two no-grad forwards per step are replayed from a HIP graph after a few eager calls
+    # (opt.graph_teacher, default on for GPU runs; see helper/graphs.py); everything else uses `model_t` itself
+    teacher = model_t
+    if getattr(opt, "graph_teacher", True) and dev.type == "cuda":
+        teacher = getattr(trainer, "_graphed_teacher", None)
+        if teacher is None or teacher.module is not model_t:
+            from .graphs import GraphedInference
+            teacher = trainer._graphed_teacher = GraphedInference(model_t)
     trace = getattr(opt, "trace", None)
 
     end = time.time()
@@ -70,7 +78,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             feat_s, logit_s = model_s(images, is_feat=True)
             with torch.no_grad():
-                feat_t, logit_t = model_t(images, is_feat=True)
+                feat_t, logit_t = teacher(images, is_feat=True)
         logit_s = logit_s.float()
         logit_t = logit_t.float()
 
@@ -94,7 +102,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                         trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
             model_t.apply(_set_bn_train)                                                  # (:314-318)
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                k, all_k = trainer._shuffle_bn(images, model_t, model_ema_head=criterion_kd.embed_t)   # (:320)
+                k, all_k = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
                 f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
             f_s, k, all_k = f_s.float(), k.float(), all_k.float()
 

@@ -621,7 +621,8 @@ def test_effnet_weight_cache_is_transparent():
 
     y0, g0 = run(False)
     y1, g1 = run(True)
-    assert torch.equal(y0, y1)
+    # (same casts, same kernels -- but the library GEMMs behind the 1x1 convolutions are not bit-reproducible run to run)
+    assert (y0.float() - y1.float()).abs().max() <= 2e-2 * y0.float().abs().max()
     assert g0.keys() == g1.keys() and all(g1[n].dtype == torch.float32 for n in g1)
     for n in g0:        # (MIOpen's bf16 weight gradients use split reductions with atomics: not bit-reproducible run to run)
         err = (g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), 1e-12)
@@ -629,7 +630,7 @@ def test_effnet_weight_cache_is_transparent():
     with torch.no_grad():
         net._conv_stem.weight.mul_(2.0)                        # an optimizer step / EMA update changes the masters ...
     y2, _ = run(True)
-    assert not torch.equal(y1, y2)                             # ... and the next forward sees it
+    assert (y2.float() - y1.float()).abs().max() > 5e-2 * y1.float().abs().max()     # ... and the next forward sees it
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         net.eval()
         assert torch.isfinite(net(x)).all()
@@ -683,3 +684,36 @@ def test_effnet_helpers_match_stock_ops(amp):
             if e > worst:
                 worst, who = e, n0
     assert worst < (0.6 if amp else 2e-2), (who, worst)
+
+
+def test_graphed_teacher_forward_matches_eager():
+    """helper/graphs.py: the no-grad forward replayed from a HIP graph gives the eager result, follows in-place weight
+    (EMA) updates, keeps updating the BatchNorm running statistics and the host-side batch counters, and falls back to
+    eager under grad mode."""
+    from moma_amd.backbones import efficientnet as E
+    from moma_amd.helper.graphs import GraphedInference
+    torch.manual_seed(0)
+    ref = E.efficientnet_b0(num_classes=3, drop_connect_rate=0.0, dropout_rate=0.0).cuda().train()
+    net = E.efficientnet_b0(num_classes=3, drop_connect_rate=0.0, dropout_rate=0.0).cuda().train()
+    net.load_state_dict(ref.state_dict())
+    g = GraphedInference(net, warmup=2)
+    xs = [torch.randn(8, 3, 64, 64, device="cuda") for _ in range(6)]
+    for i, x in enumerate(xs):
+        if i == 4:                                         # an EMA-style in-place update between replays
+            with torch.no_grad():
+                for m in (ref, net):
+                    m._conv_stem.weight.mul_(1.5)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            f0, l0 = ref(x, is_feat=True)
+            f1, l1 = g(x, is_feat=True)
+        torch.testing.assert_close(l1.float(), l0.float(), rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(f1[-1].float(), f0[-1].float(), rtol=2e-2, atol=2e-2)
+    assert len(g._graphs) == 1 and g.enabled
+    sd0, sd1 = ref.state_dict(), net.state_dict()
+    for k in sd0:
+        if "running_" in k:
+            torch.testing.assert_close(sd1[k], sd0[k], rtol=2e-2, atol=2e-2, msg=k)
+        if "num_batches_tracked" in k:
+            assert int(sd1[k]) == int(sd0[k]) == 6, k
+    y = g(xs[0])                                           # grad mode on -> plain module call
+    assert y.requires_grad
