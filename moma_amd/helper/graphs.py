@@ -57,7 +57,8 @@ class GraphedInference:
             static_x = x.clone()
             graph = torch.cuda.CUDAGraph()
             pending = [(m, m._nbt_pending) for m in self._mods if hasattr(m, "_nbt_pending")]
-            with torch.cuda.graph(graph):
+            # thread_local: other threads (RCCL's watchdog polls events) may keep calling the runtime during the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self.module(static_x, is_feat=is_feat)
             # the capture ran the Python side once without executing kernels: undo its host-side counting
             bn_train = [m for m, before in pending if m._nbt_pending != before]
