@@ -59,6 +59,8 @@ def parse():
     p.add_argument("--cpu_batch", type=int, default=16)
     p.add_argument("--cpu_steps", type=int, default=15)    # ~10 s of host work at B=16
     p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
+    p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
+                   help="queue the teacher / key side of the step on the main stream instead of a second HIP stream")
     return p.parse_args()
 
 
@@ -162,7 +164,9 @@ def make_opt(a, rank, world):
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=0.05, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
-        shuffle_bn="per_rank", num_heads=4)
+        shuffle_bn="per_rank", num_heads=4,
+        # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
+        overlap_teacher=a.overlap_teacher and os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1")
 
 
 def log(*a):

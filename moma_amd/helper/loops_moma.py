@@ -75,19 +75,21 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             images = images.contiguous(memory_format=torch.channels_last)
 
         # =================== forward =====================
-        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-            feat_s, logit_s = model_s(images, is_feat=True)
-            with torch.no_grad():
-                feat_t, logit_t = teacher(images, is_feat=True)
-        logit_s = logit_s.float()
-        logit_t = logit_t.float()
+        # opt.overlap_teacher: everything on the teacher / key side of the step (teacher forward #1, EMA, Shuffle-BN key
+        # encoding, key-side attention: all no-grad) is queued on a second HIP stream and runs concurrently with the student
+        # forward; the streams join before the losses.  Same operations in the same order per stream as the sequential
+        # loop -- the two chains do not depend on each other until the loss.
+        overlap = (getattr(opt, "overlap_teacher", False) and opt.distill == "moma" and dev.type == "cuda"
+                   and getattr(opt, "shuffle_bn", "per_rank") == "per_rank")
+        main_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
 
-        loss_cls = criterion_cls(logit_s, labels)
-        loss_div = criterion_div(logit_s, logit_t)
-
-        if opt.distill == "kd":
-            loss_kd = 0
-        elif opt.distill == "moma":
+        def teacher_side():
+            """teacher forward #1 (:270-272), then the moma branch's no-grad part (:309-320, :327-329)."""
+            nonlocal ema_ok
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None), torch.no_grad():
+                _, lt = teacher(images, is_feat=True)
+            if opt.distill != "moma":
+                return lt.float(), None, None
             student = _unwrap(model_s)
             if ema_ok is None:
                 ema_ok = _same_arch(student, model_t)
@@ -102,15 +104,43 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                         trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
             model_t.apply(_set_bn_train)                                                  # (:314-318)
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                k, all_k = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
-                f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
-            f_s, k, all_k = f_s.float(), k.float(), all_k.float()
-
-            if opt.attn == "self":                                                        # K1 (:326-329)
-                f_s = criterion_kd.atts_q(f_s)
+                kk, akk = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
+            kk, akk = kk.float(), akk.float()
+            if opt.attn == "self":                                                        # K1, key side (:327-329)
                 with torch.no_grad():
-                    k = criterion_kd.atts_k(k)
-                    all_k = criterion_kd.atts_queue(all_k)
+                    kk = criterion_kd.atts_k(kk)
+                    akk = criterion_kd.atts_queue(akk)
+            return lt.float(), kk, akk
+
+        if overlap:
+            side = getattr(trainer, "_side_stream", None)
+            if side is None:
+                side = trainer._side_stream = torch.cuda.Stream(device=dev)
+            side.wait_stream(main_stream)                     # last step's optimizer, this step's images
+            with torch.cuda.stream(side):
+                logit_t, k, all_k = teacher_side()
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            feat_s, logit_s = model_s(images, is_feat=True)
+        if overlap:
+            main_stream.wait_stream(side)
+            for t in (logit_t, k, all_k):
+                if t is not None:
+                    t.record_stream(main_stream)
+        else:
+            logit_t, k, all_k = teacher_side()
+        logit_s = logit_s.float()
+
+        loss_cls = criterion_cls(logit_s, labels)
+        loss_div = criterion_div(logit_s, logit_t)
+
+        if opt.distill == "kd":
+            loss_kd = 0
+        elif opt.distill == "moma":
+            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+                f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
+            f_s = f_s.float()
+            if opt.attn == "self":                                                        # K1, query side (:326)
+                f_s = criterion_kd.atts_q(f_s)
 
             if fused:                                                                     # K2 + K3
                 loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k)

@@ -112,6 +112,8 @@ def build_parser():
     p.add_argument("--no_fused", action="store_true", help="reference call sequence on materialised logits")
     p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic loader length")
     p.add_argument("--num_heads", type=int, default=4)
+    p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
+                   help="run the teacher / key side of the step on the main stream instead of a second HIP stream")
     p.add_argument("--no_graph_teacher", dest="graph_teacher", action="store_false",
                    help="run the teacher's two no-grad forwards eagerly instead of replaying them from a HIP graph")
     p.add_argument("--miopen_find", default="on", choices=["on", "off"],

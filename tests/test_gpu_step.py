@@ -19,8 +19,11 @@ def _sd(g, prefix):
 
 
 @pytest.mark.parametrize("ci", [0, 1])
-@pytest.mark.parametrize("fused", [True, False])
-def test_loop_matches_reference_trace(golden_dir, ci, fused):
+@pytest.mark.parametrize("fused,overlap", [(True, False), (False, False), (True, True)])
+def test_loop_matches_reference_trace(golden_dir, ci, fused, overlap):
+    """10 steps of train_distill_moma against the trace captured from the reference (G5): losses, queue pointer, final
+    queue / weights.  overlap = the teacher / key side of every step on a second HIP stream (and, from the 4th call on,
+    the teacher forwards replayed from HIP graphs): scheduling only, the numbers must not move."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from moma_amd.backbones.resnet_cifar import resnet8
@@ -38,7 +41,8 @@ def test_loop_matches_reference_trace(golden_dir, ci, fused):
     opt = argparse.Namespace(distill="moma", head=head, feat_dim=feat_dim, attn="self", mem="MoCo", nce_k=64,
                              nce_t=0.15, alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0,
                              multiprocessing_distributed=False, print_freq=1000, batch_size=8, rank=0,
-                             world_size=1, s_dim=64, t_dim=64, moma_prec="fp32", moma_fused=fused, trace=[])
+                             world_size=1, s_dim=64, t_dim=64, moma_prec="fp32", moma_fused=fused, trace=[],
+                             overlap_teacher=overlap)
     dev = torch.device("cuda", 0)
     ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
     ms.load_state_dict(_sd(g, p + "s.")); mt.load_state_dict(_sd(g, p + "t."))
