@@ -5,9 +5,7 @@ Own implementation; parameter names (conv1, bn1, layer{1,2,3}.N.{conv1,bn1,conv2
 fc) follow the reference's checkpoints (models/resnet.py:118-186) so its state_dicts load unchanged.
 Backbones stay on PyTorch-ROCm / MIOpen (out of scope as kernels).
 """
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def _conv(cin, cout, k, stride=1):

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from .. import ops
 from .base_trainer import BaseTrainer
-from .util import AverageMeter, accuracy
+from .util import accuracy
 
 
 class ContrastTrainer(BaseTrainer):

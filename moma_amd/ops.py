@@ -7,7 +7,7 @@ the HIP library.  Every wrapper refuses CPU tensors: there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterable, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import torch
 
