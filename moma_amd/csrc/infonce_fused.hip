@@ -18,32 +18,46 @@
 //   P     : exp2(X - m) in registers, packed to bf16: registers 8s..8s+7 ARE the A fragment of k-step s of
 //   P.K   : O[q, :] += P[q, keys] . K_tile  with B = keys read column-wise by ds_read_b64_tr_b16 in the
 //           permuted k order key(s,h,j) = 16s + 8(j>>2) + 4h + (j&3).
-//   The softmax reference m of a wave is FIXED to the row max of its chunk's first tile (bf16 and fp32 share
-//   the exponent range, so P may exceed 1 without losing precision) and O is never rescaled; should a later
-//   tile exceed m by more than 2^64 the wave redoes its chunk in a second pass with the true chunk max.
-//   Each WG leaves (m, l, max, O) per query row; a small combine kernel merges the chunks, adds the positive
-//   logit (exact fp32) and writes loss / lse / top-1 / dq.
+//   The softmax reference m of a query row is FIXED to the row max of its chunk's first tile + 32 (bf16 and fp32
+//   share the exponent range, so P may exceed 1 without losing precision) and O is not rescaled per tile; should a
+//   later tile exceed m by more than 2^96 the wave takes a rare in-kernel RESCUE branch: new reference for the
+//   overflowing rows, O and l of those rows rescaled once, the tile's scores recomputed against the new reference.
+//   Each WG leaves (m, l, max, O) per query row; a combine kernel merges the chunks, adds the positive
+//   logit (exact fp32) and writes loss / lse / top-1 / dq.  Two launches per call after the Q pre-pack.
 //
 // LDS image of a key tile: D/128 segments of [32 keys][128 cols] with 256-B rows,
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
 // which is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
 #include "common.hpp"
+#include <mutex>
 #include <type_traits>
 
 #ifdef MOMA_K2_STAMPS
-// Diagnostic build only (never the product): per-wave cycle sums of the pipelined loop's phases.
-__device__ unsigned long long moma_k2_stamps[1024 * 4];
-extern "C" int moma_debug_read_stamps(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned long long) * 1024 * 4);
+// Diagnostic build only (never the product): per-wave cycle stamps of the one-pass kernel.  Nothing of a stamp stays in a
+// register (the kernel has none to spare: live stamp values push it into spills): every stamp is added to / subtracted
+// from a word of LDS behind the tile ring, copied out to this buffer at the end of the kernel.
+//   word 0..2: per-tile phase sums (scores, P.K || softmax, wait + barrier); 3: entry -> first barrier; 4: first tile;
+//   5: tile loop; 6: epilogue issue.
+__device__ unsigned moma_k2_stamps[1024 * 8];
+extern "C" int moma_debug_read_stamps(unsigned* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned) * 1024 * 8);
 }
-#define K2_STAMP(var)                                                                     \
-    do {                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
-        __builtin_amdgcn_sched_barrier(0);                                                \
+#define K2_STAMP_BYTES 256
+// stamp now: word `neg` -= t, word `pos` += t  (either may be -1)
+#define K2_STAMP(neg, pos)                                                                                   \
+    do {                                                                                                     \
+        unsigned long long _t64;                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t64)::"memory");                         \
+        const unsigned _t = (unsigned)_t64;                                                                  \
+        const unsigned _a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem) + (unsigned)(NBUF * TILE_BYTES + 16 + wave * 32); \
+        if ((neg) >= 0) asm volatile("ds_sub_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((neg) < 0 ? 0 : (neg) * 4) : "memory"); \
+        if ((pos) >= 0) asm volatile("ds_add_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((pos) < 0 ? 0 : (pos) * 4) : "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
 #else
-#define K2_STAMP(var) do { } while (0)
+#define K2_STAMP_BYTES 0
+#define K2_STAMP(neg, pos) do { } while (0)
 #endif
 
 namespace moma {
@@ -111,22 +125,20 @@ __device__ __forceinline__ void dma_tile(const DmaLane& dl, const bf16_raw* __re
 
 // Q operand pre-pack: scale by log2(e)/T, round to bf16 and store in MFMA-fragment order so that every
 // workgroup of the main kernel fetches its Q tile with fully coalesced 16-B-per-lane loads:
-//   qpack[((row_tile*KS + ks)*64 + lane)] = 8 bf16 = Q[32*row_tile + (lane&31)][16*ks + 8*(lane>>5) + 0..7]
-// (rows >= B are zero).  One 64-lane "virtual wave" per 32-row tile.
+//   qpack[((row_tile*KS + ks)*64 + lane)] = 8 bf16 = Q[32*row_tile + (lane&31)][col0 + 16*ks + 8*(lane>>5) + 0..7]
+// (rows >= B are zero; col0 / dfull select a column slab of a wider q).  One 64-lane "virtual wave" per 32-row tile.
 template <int D>
-__global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restrict__ q, int B, float scale_log2,
-                                                            uint4* __restrict__ qpack, int n_row_tiles,
-                                                            int* __restrict__ any_ovf) {
+__global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restrict__ q, int B, int dfull, int col0,
+                                                            float scale_log2, uint4* __restrict__ qpack, int n_row_tiles) {
     constexpr int KS = D / 16;
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *any_ovf = 0;     // re-armed every call (graph-replay safe)
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);          // (row tile, k-step)
     if (item >= n_row_tiles * KS) return;
     const int rt = item / KS, ks = item % KS;
     const int row = rt * 32 + (lane & 31), h = lane >> 5;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (row < B) {
-        const float* qp = q + (long)row * D + 16 * ks + 8 * h;
+        const float* qp = q + (long)row * dfull + col0 + 16 * ks + 8 * h;
         a = *reinterpret_cast<const float4*>(qp);
         b = *reinterpret_cast<const float4*>(qp + 4);
     }
@@ -136,12 +148,12 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
     qpack[(long)item * 64 + lane] = __builtin_bit_cast(uint4, f);
 }
 
-// REPAIR = false: first (normally only) launch.  The softmax reference m of a wave is FIXED to the row max of
-//   its chunk's first tile: bf16 and fp32 share the 8-bit exponent, so P = 2^(x - m) may exceed 1 by many
-//   orders of magnitude without losing precision and O is never rescaled.  A wave that meets a score more than
-//   2^OVERFLOW_THR above m raises flag[chunk][wave-of-rows]; its partials are then invalid.  (m = first-tile max + REF_MARGIN)
-// REPAIR = true : second launch of the same grid; workgroups without a raised flag exit at once, flagged
-//   waves redo their chunk with m = the true chunk max the first launch recorded (x_part) -- cannot overflow.
+// The softmax reference m of a query row is FIXED to (row max of its chunk's first tile) + REF_MARGIN: bf16 and fp32
+//   share the 8-bit exponent, so P = 2^(x - m) may exceed 1 by many orders of magnitude without losing precision and O
+//   is not rescaled per tile.  A wave that meets a score more than 2^OVERFLOW_THR above a row's m takes the RESCUE branch
+//   (rare, wave-uniform): the overflowing rows get m' = that score + REF_MARGIN, their O rows and l are multiplied by
+//   2^(m - m') once, and the tile's scores are recomputed against m' (the P already formed from them is discarded before
+//   it enters O or l).  tests/test_gpu_kernels.py forces the branch (guide rule 26).
 // MODE 0: the one-pass kernel described above (d = D).
 // MODE 1 / 2: wide queues (d > 512) go through column SLABS of D <= 512 columns of the same key tiles, with the complete
 //   score tiles kept in a scratch `xs` in register order (xs[((row-wave * ntiles + tile) * 64 + lane) * 16 + r]):
@@ -154,26 +166,33 @@ struct SlabArgs {
     unsigned pitch;       // bytes between queue rows
     int first;            // MODE 1: this is the first slab (store instead of accumulate)
 };
-template <int D, bool WITH_DQ, bool REPAIR, int MODE = 0>
+
+// O partial of one wave block (32 query rows x D) in REGISTER order, 16 B per lane and store:
+//   o_part4[wave block][(c*2 + g)*64 + lane] = 4 words w = 0..3, word w = bf16 pair { O[c][8g+2w] , O[c][8g+2w+1] }
+//   = rows 16g + 4h + {0,1 | 2,3 | 8,9 | 10,11}[w] of column 32c + (lane&31), h = lane>>5
+// (O[c][r] is query row (r&3) + 8*(r>>2) + 4*h); the combine kernel gives one workgroup the 8 rows of a (block, g, h).
+__device__ __forceinline__ int opart_row(int g, int h, int w, int u) { return 16 * g + 4 * h + 8 * (w >> 1) + 2 * (w & 1) + u; }
+
+template <int D, bool WITH_DQ, int MODE = 0>
 __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, const uint4* __restrict__ qpack,
                                                    const bf16_raw* __restrict__ queue, int B, int K, int nbt,
                                                    int nchunk, int tiles_per_chunk, int Bpad,
-                                                   unsigned* __restrict__ o_part, float* __restrict__ m_part,
+                                                   uint4* __restrict__ o_part, float* __restrict__ m_part,
                                                    float* __restrict__ l_part, float* __restrict__ x_part,
-                                                   int* __restrict__ ovf_flag, SlabArgs slab = SlabArgs{}) {
-    static_assert(MODE == 0 || !REPAIR, "slab passes have no repair launch");
+                                                   SlabArgs slab = SlabArgs{}) {
     static_assert(MODE != 1 || !WITH_DQ, "score slabs carry no O");
     static_assert(MODE != 2 || WITH_DQ, "P.K slabs carry O");
     constexpr int KS = D / 16;       // k-steps of the score product
     constexpr int NCT = D / 32;      // 32-column tiles of O
     constexpr int TILE_BYTES = KT * D * 2;
+    constexpr bool PIPELINED = WITH_DQ && MODE == 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
 #ifdef MOMA_K2_STAMPS
-    unsigned long long sk0 = 0, sk1 = 0, sk2 = 0, sk3 = 0;
-    K2_STAMP(sk0);
+    if (lane < 8) reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 8 + lane] = 0u;
+    K2_STAMP(3, -1);
 #endif
 
     // block -> (query tile, key chunk): the nbt tiles of one chunk are 8 block ids apart (same XCD)
@@ -194,34 +213,67 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const DmaLane dl = dma_lane_terms<D>(lane, wave, MODE == 0 ? (unsigned)(D * 2) : slab.pitch);
     // partial slot of this wave's 32 query rows in chunk `chunk`
     const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
-    int* my_flag = ovf_flag + ((long)chunk * nbt + bt) * 4;      // 4 ints per workgroup, one per wave
 
-    bool active = true;
     float m_ref = NEG_BIG;
     if constexpr (MODE == 2) m_ref = slab.lse[min(bt * QROWS_WG + wave * 32 + n, B - 1)] * 1.4426950408889634f;
-    if constexpr (REPAIR) {
-        const int f0 = my_flag[0], f1 = my_flag[1], f2 = my_flag[2], f3 = my_flag[3];
-        if ((f0 | f1 | f2 | f3) == 0) return;                    // workgroup-uniform
-        active = my_flag[wave] != 0;                             // wave-uniform
-        m_ref = x_part[prow + n];
-    }
 
     // ---- Q fragments: B operand of X = K.Q^T ; lane (q=n, h) holds Q[q][16ks + 8h + j], pre-scaled by log2e/T,
-    //      pre-packed in fragment order by infonce_qpack_kernel (coalesced 16 B per lane)
+    //      pre-packed in fragment order by infonce_qpack_kernel (coalesced 16 B per lane).  The loads are inline asm and
+    //      counted by hand: left to hipcc, the first use of a Q register waits vmcnt(0), i.e. for every key tile of the
+    //      prologue as well (LDS-DMA and ordinary loads share the counter).
+    constexpr int PPW = D / 64;                       // DMA instructions per wave per tile
+    constexpr int NQL = (MODE != 2) ? KS : 0;         // Q load instructions per wave
     bf16x8 qf[KS];
-    if constexpr (MODE != 2) {
-        const uint4* qp = qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane;
+    auto load_q = [&]() __attribute__((always_inline)) {
+        if constexpr (MODE != 2) {
+            const char* qb = reinterpret_cast<const char*>(qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qp[ks * 64]);
-    }
+            for (int ks = 0; ks < KS; ++ks) {
+#ifndef MOMA_K2_ABL_NO_QLOAD
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[ks]) : "v"(qb + (ks >> 2) * 4096), "n"((ks & 3) * 1024) : "memory");
+#else
+                asm volatile("" : "=v"(qf[ks]) : "v"(qb));
+#endif
+            }
+        }
+    };
+#ifndef MOMA_K2_T0_FIRST
+    load_q();
+#endif
+
+    // LDS-DMA ring.  Every wave issues PPW pieces per tile, in tile order, so "all but the newest j tiles of
+    // this wave have landed" is s_waitcnt vmcnt(j*PPW); the workgroup barrier then makes the other waves'
+    // pieces visible too.  __syncthreads() would drain vmcnt to 0, hence the raw s_barrier.
+    auto wait_tiles_in_flight = [&](int j) __attribute__((always_inline)) {
+        if (j >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else if (j == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert((NBUF & (NBUF - 1)) == 0 && NBUF == 4, "ring of four tiles");
+    static_assert(3 * PPW + NQL <= 63, "vmcnt is a 6-bit counter");
+    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((unsigned)(t - t0) & (NBUF - 1)) * TILE_BYTES; };
+
+    // the whole ring is requested up front (Q first: the first score needs all of it, the tiles one after the other)
+    const int npro = min(t1 - t0, NBUF);
+#ifndef MOMA_K2_PRO
+#define MOMA_K2_PRO 4
+#endif
+    constexpr int PRO = MOMA_K2_PRO;                   // tiles requested BEFORE the first wait; the rest of the ring right after it
+    auto issue_ring = [&](auto first_pass, int jb, int je) __attribute__((always_inline)) {
+        int tb = t0;
+        asm volatile("" : "+s"(tb));                   // (opaque: the two passes do not share hoisted source addresses)
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            if (j >= jb && j < je && j < npro) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+#ifdef MOMA_K2_T0_FIRST
+            if constexpr (decltype(first_pass)::value) { if (j == 0 && jb == 0) load_q(); }
+#endif
+        }
+    };
+    issue_ring(std::true_type{}, 0, PRO);
 
     f32x16 O[WITH_DQ ? NCT : 1];
-    if constexpr (WITH_DQ) {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
-    }
     float l_run = 0.f, mx = NEG_BIG;
     int ovf = 0;
 
@@ -245,22 +297,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             for (int u = 0; u < 2; ++u) b_off[c][u] = base + (((((c ^ q4) << 2) | (e ^ (2 * u)))) << 4);
     }
 
-    // LDS-DMA ring.  Every wave issues PPW pieces per tile, in tile order, so "all but the newest j tiles of
-    // this wave have landed" is s_waitcnt vmcnt(j*PPW); the workgroup barrier then makes the other waves'
-    // pieces visible too.  __syncthreads() would drain vmcnt to 0, hence the raw s_barrier.
-    constexpr int PPW = D / 64;                       // DMA instructions per wave per tile
-    auto wait_tiles_in_flight = [&](int j) __attribute__((always_inline)) {
-        if (j >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    static_assert((NBUF & (NBUF - 1)) == 0, "ring size must be a power of two");
-    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((unsigned)(t - t0) & (NBUF - 1)) * TILE_BYTES; };
-
-    // ---- scores of one tile: X[key, q] over D.  A fragments (keys) are requested PFG groups of G k-steps ahead
+    // ---- scores of one tile: X[key, q] over D.  A fragments (keys) are requested RD k-steps ahead
     // of the MFMAs that consume them; the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the
     // reads behind the MFMAs and exposes the LDS latency once per group).  One LDS-DMA piece of the refill tile is
-    // issued after every MFMA group, so its issue cost hides behind the matrix pipe.
+    // issued after every 4th MFMA, so its issue cost hides behind the matrix pipe.
     auto score = [&](auto refill_tag, const char* buf, f32x16& x, float init, long rkey0, char* rbuf)
                      __attribute__((always_inline)) {
         // One wave per SIMD issues in order: what sits between two MFMAs runs in the shadow of the first (about 24
@@ -271,7 +311,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // exposed 4x per tile).  x starts at -m_ref ("row constant as the initial accumulator"): no subtraction later.
         // refill_tag: 0 = no refill, 1 = refill with a full tile, 2 = refill with the queue's last (partial) tile.
         constexpr int REFILL = decltype(refill_tag)::value;
-        constexpr int RD = 8;                                  // LDS read distance in k-steps (8 x 32 cycles)
+#ifndef MOMA_K2_RD
+#define MOMA_K2_RD 8
+#endif
+        constexpr int RD = MOMA_K2_RD < KS ? MOMA_K2_RD : KS;                         // LDS read distance in k-steps (RD x 32 cycles)
         static_assert(KS % 4 == 0 && KS / 4 == PPW, "one DMA piece per 4 k-steps");
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = init;
@@ -279,9 +322,14 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         unsigned aa[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) aa[c] = lbase + a_off[c];
+        static_assert(RD <= 12 && RD <= KS, "lgkmcnt is a 4-bit counter");
         f32x4 kf[RD];
         auto rd = [&](int ks) __attribute__((always_inline)) {
+#ifndef MOMA_K2_ABL_NO_SCORE_LDS
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");
+#else
+            asm volatile("" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]));
+#endif
         };
 #pragma unroll
         for (int ks = 0; ks < RD; ++ks) rd(ks);
@@ -289,9 +337,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             // reads ks+1 .. min(ks+RD-1, KS-1) may stay in flight
-            constexpr int dummy = 0; (void)dummy;
             const int ahead = (KS - 1 - ks) < (RD - 1) ? (KS - 1 - ks) : (RD - 1);
             switch (ahead) {
+                case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
                 case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
                 case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
                 case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
@@ -305,15 +356,21 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // inline-asm MFMA pins the score accumulator to VGPRs (through the builtin hipcc puts it in a[0:15] and
             // moves O's first column tile out and back every tile).  Hazards by hand: s_nop before the first MFMA
             // (VALU-written C), s_nops after the last one (VALU readers of D).
+#ifndef MOMA_K2_ABL_NO_SCORE_MFMA
             if (ks == 0)
                 asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
             else if (ks == KS - 1)
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
             else
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+#else
+            asm volatile("" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+#endif
             if (ks + RD < KS) rd(ks + RD);
             if constexpr (REFILL != 0) {
+#ifndef MOMA_K2_ABL_NO_LOOP_DMA
                 if ((ks & 3) == 1) dma_piece<D, REFILL == 2>(ks >> 2, dl, queue, rkey0, K, rbuf, wave, lane);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -334,28 +391,31 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
         }
     };
-    // tile statistics after its 16 scores were visited: true max (top-1), overflow check against the reference
-    auto tile_stats = [&](float tmax) __attribute__((always_inline)) {
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        mx = fmaxf(mx, tmax);
-        if constexpr (!REPAIR) ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
-    };
     auto pack = [&](const f32x16& p, bf16x8 (&pa)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             pa[s] = bf16x8{(__bf16)p[8 * s + 0], (__bf16)p[8 * s + 1], (__bf16)p[8 * s + 2], (__bf16)p[8 * s + 3],
                            (__bf16)p[8 * s + 4], (__bf16)p[8 * s + 5], (__bf16)p[8 * s + 6], (__bf16)p[8 * s + 7]};
     };
-    // softmax numerators of one tile, all at once (prologue tile / un-pipelined paths): x <- 2^(x - m_ref)
+    // softmax numerators of one tile of ABSOLUTE scores, all at once (prologue tile, forward-only loop, rescue):
+    //   x <- 2^(x - m_ref), l_run += row sums.  first: fixes the reference.  Otherwise a row whose tile max exceeds its
+    //   reference by more than OVERFLOW_THR moves its reference (textbook online softmax; there is no O to rescale on the
+    //   paths that can get there: the pipelined loop handles that case in its rescue branch before calling this).
     auto softmax_plain = [&](f32x16& x, int t, bool first) __attribute__((always_inline)) {
         mask_tail(x, t);
         float tmax = x[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-        if constexpr (!REPAIR) {
-            if (first) m_ref = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) + REF_MARGIN;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        mx = fmaxf(mx, tmax);
+        if (first) {
+            m_ref = tmax + REF_MARGIN;
+        } else if constexpr (!WITH_DQ) {
+            const bool o = tmax - m_ref > OVERFLOW_THR;
+            const float m_new = o ? tmax + REF_MARGIN : m_ref;
+            l_run *= __builtin_amdgcn_exp2f(m_ref - m_new);
+            m_ref = m_new;
         }
-        tile_stats(tmax);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -372,7 +432,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     auto pv = [&](const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
         if constexpr (WITH_DQ) {
-            constexpr int PF = 3;
+#ifndef MOMA_K2_PF
+#define MOMA_K2_PF 3
+#endif
+            constexpr int PF = MOMA_K2_PF;                     // column tiles of transposed reads in flight
             const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
             unsigned ba[4][2];
 #pragma unroll
@@ -384,14 +447,22 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             auto issue_lo = [&](int c) __attribute__((always_inline)) {
                 s16x4* k4 = kb[c % (PF + 1)];
                 const int imm = (c >> 2) * 8192;
+#ifndef MOMA_K2_ABL_NO_PV_LDS
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
+#else
+                asm volatile("" : "=v"(k4[0]), "=v"(k4[1]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
+#endif
             };
             auto issue_hi = [&](int c) __attribute__((always_inline)) {
                 s16x4* k4 = kb[c % (PF + 1)];
                 const int imm = (c >> 2) * 8192;
+#ifndef MOMA_K2_ABL_NO_PV_LDS
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
+#else
+                asm volatile("" : "=v"(k4[2]), "=v"(k4[3]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
+#endif
             };
 #pragma unroll
             for (int c = 0; c < PF; ++c) {
@@ -402,17 +473,26 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             for (int c = 0; c < NCT; ++c) {
                 // in flight when tile c's first MFMA issues: all of c+1 .. c+PF-1, nothing of c+PF yet
                 const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
-                if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 s16x4* k4 = kb[c % (PF + 1)];
                 const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
                 const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
+#ifndef MOMA_K2_ABL_NO_PV_MFMA
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
+#else
+                asm volatile("" ::"v"(k0), "v"(pa[0]));
+#endif
                 if (c + PF < NCT) issue_lo(c + PF);               // LDS requests in the first MFMA's shadow
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef MOMA_K2_ABL_NO_PV_MFMA
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
+#else
+                asm volatile("" ::"v"(k1), "v"(pa[1]));
+#endif
                 if (c + PF < NCT) issue_hi(c + PF);
                 between(c);                                        // one softmax step in the second MFMA's shadow
                 __builtin_amdgcn_sched_barrier(0);
@@ -420,54 +500,119 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         }
     };
 
+    // partial O of column tile c in register order, 16 B per lane and store (layout: opart_row above)
+    auto opart_dst = [&]() __attribute__((always_inline)) -> uint4* {
+        return o_part + ((long)chunk * (Bpad / 32) + bt * 4 + wave) * (long)(NCT * 2 * 64) + lane;
+    };
+    auto store_tile = [&](uint4* dst, int c) __attribute__((always_inline)) {
+        if constexpr (WITH_DQ) {
+#ifndef MOMA_K2_ABL_NO_EPI_STORE
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j)
-        if (t0 + j < t1) dma_tile<D>(dl, queue, (long)(t0 + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
-    wait_tiles_in_flight(min(t1 - t0, NBUF - 1) - 1);
-    __builtin_amdgcn_s_barrier();
+            for (int g = 0; g < 2; ++g) {
+                uint4 v;
+                v.x = (unsigned)f32_to_bf16(O[c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[c][8 * g + 1]) << 16);
+                v.y = (unsigned)f32_to_bf16(O[c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[c][8 * g + 3]) << 16);
+                v.z = (unsigned)f32_to_bf16(O[c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[c][8 * g + 5]) << 16);
+                v.w = (unsigned)f32_to_bf16(O[c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g + 7]) << 16);
+                dst[(c * 2 + g) * 64] = v;
+            }
+#else
+            asm volatile("" ::"v"(O[c]));
+#endif
+        }
+    };
 
-    if constexpr (WITH_DQ && !REPAIR && MODE == 0) {
+    // A workgroup normally makes ONE pass over its chunk.  If one of its waves met a score more than 2^OVERFLOW_THR above a
+    // row's fixed reference (its P may have overflowed), the whole workgroup -- the tile ring is shared -- repeats the chunk
+    // with the references set to the true row maxima the first pass recorded, which cannot overflow.  Rare, workgroup-uniform.
+    // (the second pass is a second copy of the code, not a loop: around a back edge hipcc's wait insertion puts a vmcnt(0)
+    // -- a full drain of the tile ring -- in front of the first pass's first softmax)
+    auto run_pass = [&](auto repass_tag) __attribute__((always_inline)) {
+    constexpr bool repass = decltype(repass_tag)::value;
+    if constexpr (repass) issue_ring(std::false_type{}, 0, PRO);
+    if constexpr (WITH_DQ) {
+        // O = 0 as the result of an MFMA on zero operands with the inline-constant accumulator 0: 16 matrix instructions
+        // issued while the first tile is on its way, instead of 256 accumulator-register writes that hipcc rematerialises
+        // between the first tile's scores and the loop.
+        bf16x8 zq = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        asm volatile("" : "+v"(zq));                      // (opaque zeros: keeps the MFMAs from being folded away)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            asm volatile("" : "+v"(zq));                  // (a fresh opaque value per tile: no common-subexpression merge)
+            O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zq, zq, z, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    l_run = 0.f;
+    mx = NEG_BIG;
+    ovf = 0;
+    // Q and tile t0 have landed (the rest of the ring stays in flight); from here on the Q registers may be read
+    wait_tiles_in_flight(min(npro, PRO) - 1);
+    if constexpr (MODE != 2) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    }
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PRO < NBUF) issue_ring(std::false_type{}, PRO, NBUF);
+    if constexpr (!repass) K2_STAMP(-1, 3);
+    if constexpr (!repass) K2_STAMP(4, -1);
+
+    if constexpr (PIPELINED) {
         // ---- software-pipelined main loop (one wave per SIMD: nothing else hides the softmax's VALU time):
         //   iteration t:  X(t+1) = scores of tile t+1            [matrix pipe; DMA pieces of tile t+3 in its shadow]
         //                 O += P(t).K(t)  ||  P(t+1) = softmax numerators of X(t+1), one register per column tile
         // Live ring slots: t, t+1 ; in flight: t+2, t+3.
         f32x16 xa;
         bf16x8 pa[2];
-        score_dispatch(slot(t0), xa, 0.f, t0 + NBUF - 1 < t1, t0 + NBUF - 1);
-        softmax_plain(xa, t0, true);
+        score_dispatch(slot(t0), xa, 0.f, false, t0);
+        softmax_plain(xa, t0, !repass);
         pack(xa, pa);
         // tile t0+1 must have landed before the loop's first score
-        wait_tiles_in_flight(min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) > 0 ? min(t0 + NBUF - 1, t1 - 1) - (t0 + 1) : 0);
+        wait_tiles_in_flight(max(min(t0 + NBUF - 1, t1 - 1) - (t0 + 1), 0));
         __builtin_amdgcn_s_barrier();
-#ifdef MOMA_K2_STAMPS
-        K2_STAMP(sk1);
+        if constexpr (!repass) K2_STAMP(-1, 4);
+        if constexpr (!repass) K2_STAMP(5, -1);
+        // every iteration of the loop has a next tile; the chunk's LAST tile is peeled off below
+#ifdef MOMA_K2_ABL_NO_LOOP
+        const int tlast = t0;
+#else
+        const int tlast = t1 - 1;
 #endif
-        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc1 = 0, acc2 = 0, acc3 = 0, accn = 0;
-        (void)st0; (void)st1; (void)st2; (void)st3; (void)acc1; (void)acc2; (void)acc3; (void)accn;
 #pragma unroll 1
-        for (int t = t0; t < t1; ++t) {
-            const bool has_next = t + 1 < t1;
+        for (int t = t0; t < tlast; ++t) {
             f32x16 xb;
-            K2_STAMP(st0);
-            if (has_next) {
-                // slot of tile t-1 (free since the barrier that ended iteration t-1) takes tile t+NBUF-1... which is
-                // tile (t+1)+NBUF-2; with NBUF = 4 the refill target during iteration t is tile t+3 -> slot of t-1
+#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
+            K2_STAMP(0, -1);
+#endif
+            {
+                // the slot of tile t-1 (free since the barrier that ended iteration t-1) takes tile t+NBUF-1
                 const bool refill = t >= t0 + 1 && t + NBUF - 1 < t1;
                 score_dispatch(slot(t + 1), xb, -m_ref, refill, t + NBUF - 1);
                 mask_tail(xb, t + 1);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xb[r] = NEG_BIG;
             }
-            K2_STAMP(st1);
+#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
+            K2_STAMP(1, 0);
+#endif
             float tmax = NEG_BIG, psum = 0.f;
             pv(slot(t), pa, [&](int c) __attribute__((always_inline)) {
-                if (c < 16) {                                   // xb already holds score - m_ref
+#ifndef MOMA_K2_ABL_NO_SOFTMAX
+                // xb already holds score - m_ref.  The exponential and the running sum are inline asm: as plain
+                // expressions hipcc sinks them to their use BEHIND the 2*NCT MFMAs of P.K (~100 issue slots that then idle
+                // the matrix pipe); volatile statements stay between the transposed reads of their column tile.  The sum
+                // lags one step, so no instruction reads a transcendental result right behind its v_exp_f32.
+                if (c < 16) {
                     tmax = fmaxf(tmax, xb[c]);
-                    xb[c] = __builtin_amdgcn_exp2f(xb[c]);
-                    psum += xb[c];
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(xb[c]));
+                    if (c >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[c - 1]));
                 }
+#endif
             });
+#ifndef MOMA_K2_ABL_NO_SOFTMAX
+            psum += xb[(NCT < 16 ? NCT : 16) - 1];
+#endif
             if constexpr (NCT < 16) {
 #pragma unroll
                 for (int c = NCT; c < 16; ++c) {
@@ -476,37 +621,41 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                     psum += xb[c];
                 }
             }
-            if (has_next) {
-                tile_stats(tmax + m_ref);                       // back to absolute log2 units
-                l_run += psum;
-                pack(xb, pa);
-            }
-            K2_STAMP(st2);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));       // relative to m_ref
+            ovf |= (tmax > OVERFLOW_THR) ? 1 : 0;
+            mx = fmaxf(mx, tmax + m_ref);                       // back to absolute log2 units
+            l_run += psum;
+            pack(xb, pa);
+#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
+            K2_STAMP(2, 1);
+#endif
             // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
             {
                 const int newest = min(t + NBUF - 1, t1 - 1);
                 wait_tiles_in_flight(newest - (t + 2) > 0 ? newest - (t + 2) : 0);
             }
             __builtin_amdgcn_s_barrier();
-            K2_STAMP(st3);
-#ifdef MOMA_K2_STAMPS
-            acc1 += st1 - st0; acc2 += st2 - st1; acc3 += st3 - st2; accn += 1;
+#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
+            K2_STAMP(-1, 2);
 #endif
         }
-#ifdef MOMA_K2_STAMPS
-        K2_STAMP(sk2);
-        if (lane == 0) {
-            const int wv = (blockIdx.x * 4 + wave) & 1023;
-            moma_k2_stamps[wv * 4 + 0] = acc1; moma_k2_stamps[wv * 4 + 1] = acc2;
-            moma_k2_stamps[wv * 4 + 2] = sk1 - sk0; moma_k2_stamps[wv * 4 + 3] = sk2 - sk1;
+        if constexpr (!repass) K2_STAMP(-1, 5);
+        if constexpr (!repass) K2_STAMP(6, -1);
+        // ---- last tile: O += P.K, with the partial of column tile c-1 converted and stored in the shadow of tile c's MFMAs
+        // (nothing else is left to hide there; done after the loop the 256 accumulator reads, 128 conversions and 32 stores
+        // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
+        {
+            uint4* dst = opart_dst();
+            pv(slot(t1 - 1), pa, [&](int c) __attribute__((always_inline)) {
+                if (c >= 1) store_tile(dst, c - 1);
+            });
+            store_tile(dst, NCT - 1);
         }
-#endif
     } else {
-        // ---- plain loop (forward-only and repair variants): score, softmax, (P.K), one tile at a time
+        // ---- plain loop (forward-only and slab variants): score, softmax, (P.K), one tile at a time
 #pragma unroll 1
         for (int t = t0; t < t1; ++t) {
-            const bool refill = t + NBUF - 1 < t1;
-            if (MODE == 0 && !active && refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
+            const bool refill = t >= t0 + 1 && t + NBUF - 1 < t1;          // slot of tile t-1, free since the last barrier
             if constexpr (MODE != 0) {
                 // slab passes: the tile's complete scores live in the scratch, 16 floats per lane in register order
                 float4* xa = reinterpret_cast<float4*>(slab.xs + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 16);
@@ -536,106 +685,73 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                     pack(x, pa);
                     pv(slot(t), pa, [&](int) __attribute__((always_inline)) {});
                 }
-            } else if (active) {
+            } else {
                 f32x16 x;
                 score_dispatch(slot(t), x, 0.f, refill, t + NBUF - 1);
                 softmax_plain(x, t, t == t0);
-                if constexpr (WITH_DQ) {
-                    bf16x8 pa[2];
-                    pack(x, pa);
-                    pv(slot(t), pa, [&](int) __attribute__((always_inline)) {});
-                }
             }
             // tile t+1 must have landed (tiles t+2.. may stay in flight); every wave must be done with this slot
-            wait_tiles_in_flight(min(t + NBUF - 1, t1 - 1) - (t + 1));
+            wait_tiles_in_flight(max(min(t + NBUF - 1, t1 - 1) - (t + 1), 0));
             __builtin_amdgcn_s_barrier();
         }
     }
 
-    // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
-    if (active) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        if (MODE == 0 && h == 0) {
-            m_part[prow + n] = m_ref;
-            l_part[prow + n] = l_tot;
-            if constexpr (!REPAIR) x_part[prow + n] = mx;
-        }
-        if constexpr (!REPAIR && MODE == 0) {
-            const int any = __any(ovf) ? 1 : 0;
-            if (lane == 0) {
-                my_flag[wave] = any;
-                if (any) atomicOr(ovf_flag + (long)nchunk * nbt * 4, 1);     // global "some wave overflowed" word
-            }
-        }
-        if constexpr (WITH_DQ) {
-            // O partial in REGISTER order, no cross-lane traffic: registers 2j and 2j+1 of a lane are two adjacent
-            // query rows of one column -> one packed bf16 pair per lane, 256 B per wave-instruction:
-            //   o_part[wave block][(c*8 + j)*64 + lane] = { O[row(2j,h)][32c+n] , O[row(2j+1,h)][32c+n] }
-            // (row(r,h) = (r&3) + 8*(r>>2) + 4*h ; the combine kernel undoes the mapping per row pair)
-            unsigned* dst = o_part + ((long)chunk * (Bpad / 32) + bt * 4 + wave) * (long)(NCT * 8 * 64) + lane;
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    dst[(c * 8 + j) * 64] = (unsigned)f32_to_bf16(O[c][2 * j]) | ((unsigned)f32_to_bf16(O[c][2 * j + 1]) << 16);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    };
+    run_pass(std::false_type{});
+    if constexpr (PIPELINED) {
+        int* wflag = reinterpret_cast<int*>(smem + NBUF * TILE_BYTES);         // 4 words behind the ring
+        const int any = __any(ovf) ? 1 : 0;
+        if (lane == 0) wflag[wave] = any;
+        __syncthreads();
+        if ((wflag[0] | wflag[1] | wflag[2] | wflag[3]) != 0) {
+            m_ref = mx;                                                          // true row maxima of the chunk
+            __syncthreads();                                                     // flags read before the ring is refilled
+            run_pass(std::true_type{});
         }
     }
+
+    // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (MODE == 0 && h == 0) {
+        m_part[prow + n] = m_ref;
+        l_part[prow + n] = l_tot;
+        x_part[prow + n] = mx;
+    }
+    if constexpr (WITH_DQ && !PIPELINED) {
+        uint4* dst = opart_dst();
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            store_tile(dst, c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#ifdef MOMA_K2_STAMPS
+    if constexpr (PIPELINED) {
+        K2_STAMP(-1, 6);
+        if (lane < 8) moma_k2_stamps[((blockIdx.x * 4 + wave) & 1023) * 8 + lane] = reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 8 + lane];
+    }
+#endif
 }
 
-template <int D, bool WITH_DQ, bool REPAIR>
+template <int D, bool WITH_DQ>
 __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const uint4* __restrict__ qpack,
                                                                const bf16_raw* __restrict__ queue, int B, int K,
                                                                int nbt, int nchunk, int tiles_per_chunk, int Bpad,
-                                                               unsigned* __restrict__ o_part, float* __restrict__ m_part,
-                                                               float* __restrict__ l_part, float* __restrict__ x_part,
-                                                               int* __restrict__ ovf_flag) {
+                                                               uint4* __restrict__ o_part, float* __restrict__ m_part,
+                                                               float* __restrict__ l_part, float* __restrict__ x_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (REPAIR) {
-        // normally nothing overflowed: one word says so and the whole (small) grid leaves at once
-        if (ovf_flag[(long)nchunk * nbt * 4] == 0) return;
-        for (int id = blockIdx.x; id < nbt * nchunk; id += gridDim.x) {
-            infonce_flash_body<D, WITH_DQ, true>(id, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad, o_part,
-                                                 m_part, l_part, x_part, ovf_flag);
-            __syncthreads();
-        }
-    } else {
-        infonce_flash_body<D, WITH_DQ, false>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
-                                              o_part, m_part, l_part, x_part, ovf_flag);
-    }
+    infonce_flash_body<D, WITH_DQ>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad, o_part, m_part,
+                                   l_part, x_part);
 }
 
 // ---- wide queues (d > 512): slab passes ------------------------------------------------------------------------
 template <int D, int MODE>
 __global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __restrict__ qpack, const bf16_raw* __restrict__ queue,
                                                               int B, int K, int nbt, int nchunk, int tiles_per_chunk, int Bpad,
-                                                              unsigned* __restrict__ o_part, SlabArgs slab) {
+                                                              uint4* __restrict__ o_part, SlabArgs slab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    infonce_flash_body<D, MODE == 2, false, MODE>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
-                                                  o_part, nullptr, nullptr, nullptr, nullptr, slab);
-}
-
-// Q columns [col0, col0 + D) of q [B, dfull] -> fragment order (as infonce_qpack_kernel, which is the col0 = 0, dfull = D case)
-template <int D>
-__global__ __launch_bounds__(256) void infonce_qpack_slab_kernel(const float* __restrict__ q, int B, int dfull, int col0,
-                                                                 float scale_log2, uint4* __restrict__ qpack, int n_row_tiles) {
-    constexpr int KS = D / 16;
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_row_tiles * KS) return;
-    const int rt = item / KS, ks = item % KS;
-    const int row = rt * 32 + (lane & 31), h = lane >> 5;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (row < B) {
-        const float* qp = q + (long)row * dfull + col0 + 16 * ks + 8 * h;
-        a = *reinterpret_cast<const float4*>(qp);
-        b = *reinterpret_cast<const float4*>(qp + 4);
-    }
-    const bf16x8 f = bf16x8{(__bf16)(a.x * scale_log2), (__bf16)(a.y * scale_log2), (__bf16)(a.z * scale_log2),
-                            (__bf16)(a.w * scale_log2), (__bf16)(b.x * scale_log2), (__bf16)(b.y * scale_log2),
-                            (__bf16)(b.z * scale_log2), (__bf16)(b.w * scale_log2)};
-    qpack[(long)item * 64 + lane] = __builtin_bit_cast(uint4, f);
+    infonce_flash_body<D, MODE == 2, MODE>(blockIdx.x, smem, qpack, queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
+                                           o_part, nullptr, nullptr, nullptr, slab);
 }
 
 // softmax statistics of the finished score scratch: wave = (row-wave rw, split of the key tiles); online max per lane,
@@ -690,14 +806,14 @@ __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __
 __global__ __launch_bounds__(256) void infonce_slab_dq_kernel(const unsigned* __restrict__ o_part, const float* __restrict__ k,
                                                               const float* __restrict__ loss_rows, float* __restrict__ dq, int B,
                                                               int dfull, int col0, int D, float inv_T, int nchunk, int Bpad) {
-    // block = one pair of rows (2m, 2m+1), threads over the slab's columns
+    // block = one pair of rows (2m, 2m+1) = one packed word (g, h, w) of the partial layout, threads over the slab's columns
     const int row0 = blockIdx.x * 2;
-    const int qq = row0 & 31, h = (qq >> 2) & 1, r0 = (qq & 3) + 4 * (qq >> 3), j = r0 >> 1;
+    const int qq = row0 & 31, g = (qq >> 4) & 1, h = (qq >> 2) & 1, w = ((qq >> 3) & 1) * 2 + ((qq >> 1) & 1);
     const int nct = D / 32;
-    const long wb_stride = (long)nct * 8 * 64, chunk_stride = (long)(Bpad / 32) * wb_stride;
-    const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + j * 64 + 32 * h;
+    const long wb_stride = (long)nct * 2 * 64 * 4, chunk_stride = (long)(Bpad / 32) * wb_stride;       // in 4-byte words
+    const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + (g * 64 + 32 * h) * 4 + w;
     for (int col = threadIdx.x; col < D; col += blockDim.x) {
-        const unsigned* src = base + (long)(col >> 5) * 8 * 64 + (col & 31);
+        const unsigned* src = base + ((long)(col >> 5) * 2 * 64 + (col & 31)) * 4;
         float a0 = 0.f, a1 = 0.f;
         for (int c = 0; c < nchunk; ++c) {
             const unsigned v = src[(long)c * chunk_stride];
@@ -715,110 +831,116 @@ __global__ __launch_bounds__(256) void infonce_slab_dq_kernel(const unsigned* __
     }
 }
 
-// merge the key chunks of a PAIR of adjacent query rows (2m, 2m+1 -- they share the packed O words), add the
-// positive logit (exact fp32), emit loss / lse / top-1 / dq.  128 threads per row for the scalars; for dq the 256
-// threads are 4 chunk-groups x 64 lanes, a lane owning 4 adjacent packed words (16-B loads = 4 columns x 2 rows).
+// merge the key chunks of the 8 query rows of one (wave block, g, h) group -- they share the packed 16-B O words -- for one
+// group of 64 columns: add the positive logit (exact fp32), emit loss / lse / top-1 (column group 0 only) and dq.
+// Scalars: 32 threads per row.  dq: the 256 threads are 4 chunk-groups x 64 columns, one 16-B load (8 rows of a column) per
+// thread and chunk; the chunk-groups are summed through LDS in a fixed order (bitwise reproducible).
+constexpr int COMBINE_MAX_CHUNKS = 1024;
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                int B, int D, float inv_T, int nchunk, int Bpad,
-                                                               const unsigned* __restrict__ o_part,
+                                                               const uint4* __restrict__ o_part,
                                                                const float* __restrict__ m_part,
                                                                const float* __restrict__ l_part,
                                                                const float* __restrict__ x_part,
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq) {
-    __shared__ float red[2][2];
-    __shared__ float wts[2][1024];
-    __shared__ float accs[4][2][520];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int rsel = tid >> 7;                       // which row of the pair this half of the block reduces
-    const int t128 = tid & 127;
-    const int b = blockIdx.x * 2 + rsel;
-    const bool live = b < B;
-    const int bb = live ? b : B - 1;
+    __shared__ __attribute__((aligned(16))) float wts[COMBINE_MAX_CHUNKS][8];
+    __shared__ float accs[4][8][64];
+    __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
+    const int tid = threadIdx.x;
+    const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    auto pair_sum = [&](float v) { v = wave_sum(v); __syncthreads(); if (lane == 0) red[rsel][wid & 1] = v; __syncthreads(); return red[rsel][0] + red[rsel][1]; };
-    auto pair_max = [&](float v) { v = wave_max(v); __syncthreads(); if (lane == 0) red[rsel][wid & 1] = v; __syncthreads(); return fmaxf(red[rsel][0], red[rsel][1]); };
-    // positive logit
-    float s = 0.f;
-    for (int c = t128; c < D; c += 128) s = fmaf(q[(long)bb * D + c], k[(long)bb * D + c], s);
-    const float s0 = pair_sum(s) * inv_T;
-    const float s0l = s0 * LOG2E;
-    float M = NEG_BIG, X = NEG_BIG;
-    for (int c = t128; c < nchunk; c += 128) {
-        M = fmaxf(M, m_part[(long)c * Bpad + bb]);
-        X = fmaxf(X, x_part[(long)c * Bpad + bb]);
-    }
-    M = fmaxf(pair_max(M), s0l);
-    X = pair_max(X);
-    float L = 0.f;
-    for (int c = t128; c < nchunk; c += 128) {
-        const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
-        wts[rsel][c] = w;
-        L += w * l_part[(long)c * Bpad + bb];
-    }
-    const float p0u = exp2f(s0l - M);
-    L = pair_sum(L) + p0u;
-    const float lse = (M + log2f(L)) * LN2;
-    if (t128 == 0 && live) {
-        lse_out[b] = lse;
-        loss_rows[b] = lse - s0;
-        top1[b] = (s0l >= X) ? 1 : 0;
-    }
-    if (dq != nullptr) {
-        // rows 2m, 2m+1 -> wave block, register pair j, lane half h  (q = row & 31 = (r&3) + 8*(r>>2) + 4*h)
-        const int row0 = blockIdx.x * 2;
-        const int qq = row0 & 31, h = (qq >> 2) & 1, r0 = (qq & 3) + 4 * (qq >> 3), j = r0 >> 1;
-        const int nct = D / 32;
-        const long wb_stride = (long)nct * 8 * 64;                      // words per wave block
-        const long chunk_stride = (long)(Bpad / 32) * wb_stride;
-        const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + j * 64 + 32 * h;
-        const int g = tid >> 6, tg = tid & 63;
-        __syncthreads();                                                 // wts[][] complete
-        for (int c4 = tg; c4 < D / 4; c4 += 64) {                       // 4 adjacent columns: same column tile
-            const int col = c4 * 4, c = col >> 5, n = col & 31;
-            const uint4* src = reinterpret_cast<const uint4*>(base + (long)c * 8 * 64 + n);
-            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-            int jc = g;
-            for (; jc + 12 < nchunk; jc += 16) {
-                uint4 v[4];
+    auto row_of = [&](int i) { return wb * 32 + opart_row(g, h, i >> 1, i & 1); };
+    auto sum32 = [](float v) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(src) + (long)(jc + 4 * u) * chunk_stride);
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    auto max32 = [](float v) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float w0 = wts[0][jc + 4 * u], w1 = wts[1][jc + 4 * u];
-                    const unsigned vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a0[i] = fmaf(w0, __uint_as_float(vv[i] << 16), a0[i]);
-                        a1[i] = fmaf(w1, __uint_as_float(vv[i] & 0xffff0000u), a1[i]);
-                    }
-                }
-            }
-            for (; jc < nchunk; jc += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(src) + (long)jc * chunk_stride);
-                const float w0 = wts[0][jc], w1 = wts[1][jc];
-                const unsigned vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a0[i] = fmaf(w0, __uint_as_float(vv[i] << 16), a0[i]);
-                    a1[i] = fmaf(w1, __uint_as_float(vv[i] & 0xffff0000u), a1[i]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                accs[g][0][col + i] = a0[i];
-                accs[g][1][col + i] = a1[i];
+        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    {
+        const int rr = tid >> 5, l32 = tid & 31;
+        const int b = row_of(rr);
+        const bool live = b < B;
+        const int bb = live ? b : B - 1;
+        float s = 0.f;                                                   // positive logit
+        for (int c = l32 * 4; c < D; c += 128) {
+            const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);
+            const float4 ka = *reinterpret_cast<const float4*>(k + (long)bb * D + c);
+            s = fmaf(qa.x, ka.x, s); s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
+        }
+        const float s0 = sum32(s) * inv_T;
+        const float s0l = s0 * LOG2E;
+        float M = NEG_BIG, X = NEG_BIG;
+        for (int c = l32; c < nchunk; c += 32) {
+            M = fmaxf(M, m_part[(long)c * Bpad + bb]);
+            X = fmaxf(X, x_part[(long)c * Bpad + bb]);
+        }
+        M = fmaxf(max32(M), s0l);
+        X = max32(X);
+        float L = 0.f;
+        for (int c = l32; c < nchunk; c += 32) {
+            const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
+            wts[c][rr] = w;
+            L += w * l_part[(long)c * Bpad + bb];
+        }
+        const float p0u = exp2f(s0l - M);
+        L = sum32(L) + p0u;
+        const float lse = (M + log2f(L)) * LN2;
+        if (l32 == 0) {
+            rowc[rr][0] = 1.f / L;
+            rowc[rr][1] = p0u / L - 1.f;
+            if (live && blockIdx.y == 0) {
+                lse_out[b] = lse;
+                loss_rows[b] = lse - s0;
+                top1[b] = (s0l >= X) ? 1 : 0;
             }
         }
-        __syncthreads();
-        if (live) {
-            const float invL = 1.f / L;
-            const float cpos = p0u * invL - 1.f;
-            for (int c = t128; c < D; c += 128) {
-                const float acc = accs[0][rsel][c] + accs[1][rsel][c] + accs[2][rsel][c] + accs[3][rsel][c];
-                const long o = (long)b * D + c;
-                dq[o] = (cpos * k[o] + acc * invL) * inv_T;
-            }
+    }
+    if (dq == nullptr) return;
+    __syncthreads();                                                     // wts[][], rowc[][] complete
+    const int col = tid & 63, cg = tid >> 6;
+    const int column = blockIdx.y * 64 + col, c = column >> 5, n = column & 31;
+    const int nct = D / 32;
+    const long wb_stride = (long)nct * 2 * 64;                           // uint4 per wave block
+    const long chunk_stride = (long)(Bpad / 32) * wb_stride;
+    const uint4* src = o_part + (long)wb * wb_stride + (c * 2 + g) * 64 + h * 32 + n;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto fma8 = [&](const uint4& v, int ck) {
+        const float4 w0 = *reinterpret_cast<const float4*>(&wts[ck][0]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&wts[ck][4]);
+        acc[0] = fmaf(w0.x, __uint_as_float(v.x << 16), acc[0]);
+        acc[1] = fmaf(w0.y, __uint_as_float(v.x & 0xffff0000u), acc[1]);
+        acc[2] = fmaf(w0.z, __uint_as_float(v.y << 16), acc[2]);
+        acc[3] = fmaf(w0.w, __uint_as_float(v.y & 0xffff0000u), acc[3]);
+        acc[4] = fmaf(w1.x, __uint_as_float(v.z << 16), acc[4]);
+        acc[5] = fmaf(w1.y, __uint_as_float(v.z & 0xffff0000u), acc[5]);
+        acc[6] = fmaf(w1.z, __uint_as_float(v.w << 16), acc[6]);
+        acc[7] = fmaf(w1.w, __uint_as_float(v.w & 0xffff0000u), acc[7]);
+    };
+    int ck = cg;
+    for (; ck + 28 < nchunk; ck += 32) {                                 // 8 loads in flight per lane
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(ck + 4 * u) * chunk_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fma8(v[u], ck + 4 * u);
+    }
+    for (; ck < nchunk; ck += 4) fma8(src[(long)ck * chunk_stride], ck);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accs[cg][i][col] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int i = cg + 4 * half;
+        const int b = row_of(i);
+        if (b < B) {
+            const float a = ((accs[0][i][col] + accs[1][i][col]) + accs[2][i][col]) + accs[3][i][col];
+            const long o = (long)b * D + column;
+            dq[o] = (rowc[i][1] * k[o] + a * rowc[i][0]) * inv_T;
         }
     }
 }
@@ -858,103 +980,89 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     const int ds = d > 512 ? 512 : d;                        // widest slab
-    size_t bytes = rows * ds * 2 + 3 * rows * sizeof(float) + ((size_t)p.nchunk * p.nbt * 4 + 4) * sizeof(int) +
-                   (size_t)p.Bpad * ds * 2 + 1024;
+    size_t bytes = rows * ds * 2 + 3 * rows * sizeof(float) + (size_t)p.Bpad * ds * 2 + 1024;
     if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 256;     // score scratch
     return bytes;
 }
+
+namespace {
+// dynamic-LDS opt-in of every instantiation, once per process (hipFuncSetAttribute is not a stream operation)
+std::once_flag g_lds_attr_once;
+void set_lds_attrs() {
+    const int mx = NBUF * KT * 512 * 2 + 16 + K2_STAMP_BYTES;
+#define MOMA_SET_LDS(DD)                                                                                                        \
+    (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);     \
+    (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);    \
+    (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);         \
+    (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
+    MOMA_SET_LDS(512); MOMA_SET_LDS(384); MOMA_SET_LDS(256); MOMA_SET_LDS(128);
+#undef MOMA_SET_LDS
+}
+}  // namespace
 
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
     const FlashPlan p = plan(B, K);
+    if (p.nchunk > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     const int dsl = d > 512 ? 512 : d;
     float* m_part = (float*)ws;
     float* l_part = m_part + rows;
     float* x_part = l_part + rows;
-    int* flags = (int*)(x_part + rows);
-    unsigned* o_part = (unsigned*)(((uintptr_t)(flags + (size_t)p.nchunk * p.nbt * 4 + 4) + 255) & ~(uintptr_t)255);
-    uint4* qpack = (uint4*)(((uintptr_t)(o_part + rows * (dsl / 2)) + 255) & ~(uintptr_t)255);
+    uint4* o_part = (uint4*)(((uintptr_t)(x_part + rows) + 255) & ~(uintptr_t)255);
+    uint4* qpack = (uint4*)(((uintptr_t)((char*)o_part + rows * dsl * 2) + 255) & ~(uintptr_t)255);
+    std::call_once(g_lds_attr_once, set_lds_attrs);
+    const float scale_log2 = inv_T * 1.4426950408889634f;
+    const bf16_raw* qu = (const bf16_raw*)queue;
+    const dim3 grid(p.nbt * p.nchunk), block(256);
     if (d > 512) {
         // ---- wide queue: column slabs.  scores -> scratch (one launch per slab), statistics, lse / loss / top-1, then
         //      per slab P.K and the slab's columns of dq
         float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * dsl * 2) + 255) & ~(uintptr_t)255);
         const int ntiles = (K + KT - 1) / KT;
-        const float scale_log2s = inv_T * 1.4426950408889634f;
-        const bf16_raw* qu0 = (const bf16_raw*)queue;
-        static bool slab_attr = false;
-        if (!slab_attr) {
-#define MOMA_SLAB_LDS(DD) (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * KT * 512 * 2); \
-                          (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * KT * 512 * 2)
-            MOMA_SLAB_LDS(512); MOMA_SLAB_LDS(384); MOMA_SLAB_LDS(256); MOMA_SLAB_LDS(128);
-#undef MOMA_SLAB_LDS
-            slab_attr = true;
-        }
-        const dim3 sgrid(p.nbt * p.nchunk), sblock(256);
         auto slab_width = [&](int col0) { const int rem = d - col0; return rem >= 512 ? 512 : rem; };   // 512.., then 384/256/128
         if (ev_begin) (void)hipEventRecord(ev_begin, st);
         for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
             const int D = slab_width(col0);
             const SlabArgs sa{xs, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
-            const size_t slds = (size_t)NBUF * KT * D * 2;
+            const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
 #define MOMA_SLAB_SCORES(DD)                                                                                             \
             do {                                                                                                         \
-                hipLaunchKernelGGL((infonce_qpack_slab_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2s, qpack, p.Bpad / 32); \
-                hipLaunchKernelGGL((infonce_slab_kernel<DD, 1>), sgrid, sblock, slds, st, qpack, qu0 + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa); \
+                hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2, qpack, p.Bpad / 32); \
+                hipLaunchKernelGGL((infonce_slab_kernel<DD, 1>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa); \
             } while (0)
             if (D == 512) MOMA_SLAB_SCORES(512); else if (D == 384) MOMA_SLAB_SCORES(384); else if (D == 256) MOMA_SLAB_SCORES(256); else MOMA_SLAB_SCORES(128);
 #undef MOMA_SLAB_SCORES
         }
         hipLaunchKernelGGL(infonce_slab_stats_kernel, dim3(((p.Bpad / 32) * p.nchunk + 3) / 4), dim3(256), 0, st, xs, K, ntiles,
                            p.Bpad, p.nchunk, m_part, l_part, x_part);
-        hipLaunchKernelGGL(infonce_combine_kernel, dim3((B + 1) / 2), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
+        hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
                            m_part, l_part, x_part, loss_rows, lse, top1, (float*)nullptr);
         if (dq) {
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
                 const int D = slab_width(col0);
                 const SlabArgs sa{xs, lse, (unsigned)(d * 2), 0};
-                const size_t slds = (size_t)NBUF * KT * D * 2;
-#define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), sgrid, sblock, slds, st, qpack, qu0 + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa)
+                const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
+#define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa)
                 if (D == 512) MOMA_SLAB_PV(512); else if (D == 384) MOMA_SLAB_PV(384); else if (D == 256) MOMA_SLAB_PV(256); else MOMA_SLAB_PV(128);
 #undef MOMA_SLAB_PV
-                hipLaunchKernelGGL(infonce_slab_dq_kernel, dim3((B + 1) / 2), dim3(256), 0, st, o_part, k, loss_rows, dq, B, d, col0, D,
-                                   inv_T, p.nchunk, p.Bpad);
+                hipLaunchKernelGGL(infonce_slab_dq_kernel, dim3((B + 1) / 2), dim3(256), 0, st, (const unsigned*)o_part, k, loss_rows, dq,
+                                   B, d, col0, D, inv_T, p.nchunk, p.Bpad);
             }
         }
         if (ev_end) (void)hipEventRecord(ev_end, st);          // (the measurement hook spans every pass of the slab path)
         return hipGetLastError();
     }
-    const float scale_log2 = inv_T * 1.4426950408889634f;
-    const dim3 grid(p.nbt * p.nchunk), block(256);
-    const dim3 rgrid(min(p.nbt * p.nchunk, 16));     // repair pass: a handful of workgroups walk the (normally empty) list
-    const size_t lds = (size_t)NBUF * KT * d * 2;
-    const bf16_raw* qu = (const bf16_raw*)queue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        const int mx = NBUF * KT * 512 * 2;
-#define MOMA_SET_LDS(DD, A, Bx) (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, A, Bx>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
-        MOMA_SET_LDS(512, true, false); MOMA_SET_LDS(512, true, true); MOMA_SET_LDS(512, false, false); MOMA_SET_LDS(512, false, true);
-        MOMA_SET_LDS(384, true, false); MOMA_SET_LDS(384, true, true); MOMA_SET_LDS(384, false, false); MOMA_SET_LDS(384, false, true);
-        MOMA_SET_LDS(256, true, false); MOMA_SET_LDS(256, true, true); MOMA_SET_LDS(256, false, false); MOMA_SET_LDS(256, false, true);
-        MOMA_SET_LDS(128, true, false); MOMA_SET_LDS(128, true, true); MOMA_SET_LDS(128, false, false); MOMA_SET_LDS(128, false, true);
-#undef MOMA_SET_LDS
-        attr_done = true;
-    }
-#define MOMA_FLASH_ARGS qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part, flags
+    const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
+#define MOMA_FLASH_ARGS qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part
 #define MOMA_FLASH_LAUNCH(DD)                                                                             \
     do {                                                                                                  \
-        hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, scale_log2, qpack, p.Bpad / 32, flags + (size_t)p.nchunk * p.nbt * 4); \
+        hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
         if (ev_begin) (void)hipEventRecord(ev_begin, st);                                                 \
-        if (dq) {                                                                                         \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, true, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
-            if (ev_end) (void)hipEventRecord(ev_end, st);                                                 \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, true, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
-        } else {                                                                                          \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, false, false>), grid, block, lds, st, MOMA_FLASH_ARGS); \
-            if (ev_end) (void)hipEventRecord(ev_end, st);                                                 \
-            hipLaunchKernelGGL((infonce_flash_kernel<DD, false, true>), rgrid, block, lds, st, MOMA_FLASH_ARGS);  \
-        }                                                                                                 \
+        if (dq) hipLaunchKernelGGL((infonce_flash_kernel<DD, true>), grid, block, lds, st, MOMA_FLASH_ARGS);  \
+        else hipLaunchKernelGGL((infonce_flash_kernel<DD, false>), grid, block, lds, st, MOMA_FLASH_ARGS);    \
+        if (ev_end) (void)hipEventRecord(ev_end, st);                                                     \
     } while (0)
     if (d == 512) MOMA_FLASH_LAUNCH(512);
     else if (d == 384) MOMA_FLASH_LAUNCH(384);
@@ -964,8 +1072,8 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(infonce_combine_kernel, dim3((B + 1) / 2), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
-                       m_part, l_part, x_part, loss_rows, lse, top1, dq);
+    hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 64 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
+                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq);
     return hipGetLastError();
 }
 

@@ -60,10 +60,11 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
     # (opt.graph_teacher, default on for GPU runs; see helper/graphs.py); everything else uses `model_t` itself
     teacher = model_t
     if getattr(opt, "graph_teacher", True) and dev.type == "cuda":
-        teacher = getattr(trainer, "_graphed_teacher", None)
+        holder = trainer if trainer is not None else opt          # (--distill kd runs without a ContrastTrainer)
+        teacher = getattr(holder, "_graphed_teacher", None)
         if teacher is None or teacher.module is not model_t:
             from .graphs import GraphedInference
-            teacher = trainer._graphed_teacher = GraphedInference(model_t)
+            teacher = holder._graphed_teacher = GraphedInference(model_t)
     trace = getattr(opt, "trace", None)
 
     end = time.time()

@@ -3,6 +3,7 @@
 from __future__ import print_function
 
 import json
+import math
 import os
 
 import numpy as np
@@ -11,14 +12,20 @@ import torch.distributed as dist
 
 
 def adjust_learning_rate(epoch, opt, optimizer):
-    """Step decay: lr * rate^(#decay epochs passed)   (helper/util.py:37-50)."""
-    steps = np.sum(epoch > np.asarray(opt.lr_decay_epochs))
-    new_lr = opt.learning_rate
-    if steps > 0:
-        new_lr = opt.learning_rate * (opt.lr_decay_rate ** steps)
-        for g in optimizer.param_groups:
-            g["lr"] = new_lr
-    return new_lr
+    """The epoch schedule of the reference trainer (helper/util.py:37-50, called at train_student_moma.py:484):
+    --cosine -> cosine from lr down to eta_min = lr * rate^3 over opt.epochs, otherwise step decay
+    lr * rate^(#decay epochs passed); the lr of EVERY param group is rewritten each epoch.  Returns the lr."""
+    lr = opt.learning_rate
+    if getattr(opt, "cosine", False):
+        eta_min = lr * (opt.lr_decay_rate ** 3)
+        lr = eta_min + (lr - eta_min) * (1 + math.cos(math.pi * epoch / opt.epochs)) / 2
+    else:
+        steps = np.sum(epoch > np.asarray(opt.lr_decay_epochs))
+        if steps > 0:
+            lr = lr * (opt.lr_decay_rate ** steps)
+    for g in optimizer.param_groups:
+        g["lr"] = lr
+    return lr
 
 
 class AverageMeter(object):

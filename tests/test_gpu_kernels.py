@@ -199,21 +199,24 @@ def test_infonce_flash_queue_term(ops, B, d, K):
     assert err.max() < 2e-2, err.max()
 
 
+@pytest.mark.parametrize("grad", [True, False])
+@pytest.mark.parametrize("d", [256, 512])
 @pytest.mark.parametrize("scale", [30.0, 25.0, 10.0, 6.0])
-def test_infonce_flash_overflow_repair(ops, scale):
+def test_infonce_flash_overflow_repass(ops, scale, d, grad):
     """A key far down the chunk beats the first tile's max by tens to hundreds of log2 units.  Beyond the fixed
-    reference's headroom (128) the first launch flags the wave and the repair launch redoes the chunk with the true
-    chunk max (rule 26: force the rare branch, full reference: scale 30 / 25 -> ~290 / 240 log2 units); below it
-    (scale 10 / 6 -> ~96 / 58) the single pass must carry the range by itself."""
+    reference's headroom (128) the wave raises its overflow word and the WORKGROUP repeats its chunk in-kernel with the
+    true row maxima as references (rule 26: force the rare branch, full reference: scale 30 / 25 -> ~290 / 240 log2
+    units); below it (scale 10 / 6 -> ~96 / 58) the single pass must carry the range by itself.  Without a gradient the
+    forward-only kernel runs, which moves its reference on the fly (online softmax, no O to rescale)."""
     rng = np.random.default_rng(7)
-    B, d, K, T = 40, 256, 3000, 0.15
+    B, K, T = 40, 3000, 0.15
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
     # rows 5 and 17 see a huge logit at keys 1500 / 2999 (late tiles of their chunks): s = |q|*30/T ~ 200 nats
     queue[1500] = scale * q[5] / np.linalg.norm(q[5])
     queue[2999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
-    tq = _t(q).requires_grad_(True)
+    tq = _t(q).requires_grad_(grad)
     tqueue = _t(queue, torch.bfloat16)
     qe = tqueue.float().cpu().numpy()
     ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
@@ -223,8 +226,39 @@ def test_infonce_flash_overflow_repair(ops, scale):
     np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=1e-2, atol=2e-2)
     assert np.all(np.isfinite(lse.cpu().numpy()))
     assert abs(loss_rows.mean().item() - ref["loss"]) < 1e-2 * abs(ref["loss"])
-    loss_rows.sum().backward()
-    np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
+    if grad:
+        loss_rows.sum().backward()
+        np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
+
+
+def test_infonce_flash_forward_only_matches_grad_path(ops):
+    """The forward-only kernel (no dq requested) and the pipelined kernel give the same loss / lse / top-1."""
+    rng = np.random.default_rng(11)
+    for B, d, K in [(256, 512, 8192), (70, 128, 2000), (129, 384, 5000)]:
+        q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+        k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+        queue = _t(O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32)), torch.bfloat16)
+        a = ops.infonce_fused(_t(q).requires_grad_(True), _t(k), queue, 0.15, "bf16")
+        b = ops.infonce_fused(_t(q), _t(k), queue, 0.15, "bf16")
+        np.testing.assert_allclose(a[0].detach().cpu().numpy(), b[0].cpu().numpy(), rtol=0, atol=1e-4)
+        np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=0, atol=1e-4)
+        assert torch.equal(a[2], b[2])
+
+
+def test_infonce_fused_bitwise_repeatable(ops):
+    """Two launches on the same inputs give bit-identical loss and dq (no atomics anywhere in the one-pass call)."""
+    rng = np.random.default_rng(3)
+    B, d, K = 256, 512, 16384
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = _t(O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32)), torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        tq = _t(q).requires_grad_(True)
+        lr, lse, _ = ops.infonce_fused(tq, _t(k), queue, 0.15, "bf16")
+        lr.sum().backward()
+        outs.append((lr.detach().clone(), tq.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 # ------------------------------------------------------------------------------------------------ K1
