@@ -349,6 +349,10 @@ def main():
                        "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank"},
             "roofline": roof,
         }
+        if world > 1:      # what the N>1 line was measured with (the driver checks it against its own launch)
+            out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "collective": "DDP bucketed gradient all-reduce (student) + one flat async all-reduce of the "
+                                         "trainable criterion modules per step; per-rank queue, no data-path gather"}
         log(f"timed region: {dt:.2f} s; {out['value']} images/sec")
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU restatement (bounded sample) ...")

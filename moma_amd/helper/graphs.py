@@ -15,9 +15,17 @@ import torch
 
 
 class GraphedInference:
-    def __init__(self, module, warmup: int = 3):
+    """Contract of the returned values: `model(x, is_feat=True)` gives `([pooled_feature], logits)` -- ONLY the last
+    (pooled) feature, cloned, and the cloned logits; the intermediate feature maps live in the graph's static memory,
+    are overwritten by the next replay and are therefore not handed out (the MoMA loop reads `feat[-1]` and the logits
+    only; a caller that needs the whole list passes `full_feats=True` and gets an eager forward).  At most `max_graphs`
+    (shape, autocast, train/eval) variants are captured -- each holds a private activation pool; further variants (a
+    ragged last batch, another image size) run eagerly."""
+
+    def __init__(self, module, warmup: int = 3, max_graphs: int = 4):
         self.module = module
         self.warmup = warmup
+        self.max_graphs = max_graphs
         self.enabled = os.environ.get("MOMA_GRAPH_TEACHER", "1") == "1"
         self._seen = {}
         self._graphs = {}
@@ -32,19 +40,20 @@ class GraphedInference:
         modes = hash(tuple(m.training for m in self._mods))
         return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes)
 
-    def __call__(self, x, is_feat=False):
-        if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
+    def __call__(self, x, is_feat=False, full_feats=False):
+        if full_feats or not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
             return self.module(x, is_feat=is_feat)
         key = self._key(x, is_feat)
         entry = self._graphs.get(key)
         if entry is None:
             n = self._seen.get(key, 0) + 1
-            self._seen[key] = n
-            if n <= self.warmup:
-                return self.module(x, is_feat=is_feat)
+            if len(self._seen) < 64 or key in self._seen:
+                self._seen[key] = n
+            if n <= self.warmup or len(self._graphs) >= self.max_graphs:
+                return self._trim(self.module(x, is_feat=is_feat), is_feat)
             entry = self._capture(key, x, is_feat)
             if entry is None:
-                return self.module(x, is_feat=is_feat)
+                return self._trim(self.module(x, is_feat=is_feat), is_feat)
         graph, static_x, out, bn_train = entry
         static_x.copy_(x)
         graph.replay()
@@ -74,9 +83,16 @@ class GraphedInference:
 
     @staticmethod
     def _detach_outputs(out, is_feat):
-        """Static graph outputs are overwritten by the next replay: the small tensors callers keep across it (pooled
-        feature, logits) are cloned, the large intermediate features are handed out as they are."""
+        """Static graph outputs are overwritten by the next replay: what is handed out (pooled feature, logits) is cloned."""
         if is_feat:
             feats, logits = out
-            return list(feats[:-1]) + [feats[-1].clone()], logits.clone()
+            return [feats[-1].clone()], logits.clone()
         return out.clone()
+
+    @staticmethod
+    def _trim(out, is_feat):
+        """Eager calls return the same shape of result as replays (one contract whatever path served the call)."""
+        if is_feat:
+            feats, logits = out
+            return [feats[-1]], logits
+        return out

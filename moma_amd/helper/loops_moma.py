@@ -55,7 +55,9 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         dev = torch.device("cuda", opt.gpu if (opt.gpu is not None and opt.multiprocessing_distributed) else 0) \
             if torch.cuda.is_available() else torch.device("cpu")
     ema_ok = None
-    kd_params = None
+    if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
+        # one flat all-reduce per step for the trainable criterion modules, launched from autograd hooks (overlaps backward)
+        trainer.attach_grad_sync([p for p in criterion_kd.parameters() if p.requires_grad])
     # the teacher's two no-grad forwards per step are replayed from a HIP graph after a few eager calls
     # (opt.graph_teacher, default on for GPU runs; see helper/graphs.py); everything else uses `model_t` itself
     teacher = model_t
@@ -82,6 +84,10 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         # loop -- the two chains do not depend on each other until the loss.
         overlap = (getattr(opt, "overlap_teacher", False) and opt.distill == "moma" and dev.type == "cuda"
                    and getattr(opt, "shuffle_bn", "per_rank") == "per_rank")
+        if (idx == 0 and epoch <= 1 and getattr(opt, "overlap_teacher", False) and not overlap and dev.type == "cuda"
+                and opt.distill == "moma" and getattr(opt, "rank", 0) == 0):
+            print("[moma] --shuffle_bn gather: the teacher side stays on the main stream (its collectives are ordered "
+                  "with the DDP all-reduce there); overlap_teacher is off in this mode")
         main_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
 
         def teacher_side():
@@ -157,7 +163,8 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         loss = opt.cls * loss_cls + opt.div * loss_div + opt.beta * loss_kd
         losses.update(loss.detach(), images.size(0))
         if trace is not None:           # optional per-step record (tests / benchmarking), device tensors
-            trace.append((loss.detach(), contrast.index if contrast is not None else None))
+            trace.append((loss.detach(), contrast.index if contrast is not None else None,
+                          loss_kd.detach() if torch.is_tensor(loss_kd) else loss_kd))
 
         # =================== metrics =====================
         top1.update(accuracy(logit_s, labels, topk=(1,))[0].squeeze(0), images.size(0))
@@ -169,9 +176,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         else:
             loss.backward()
         if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
-            if kd_params is None:
-                kd_params = [p for p in criterion_kd.parameters() if p.requires_grad]
-            trainer.allreduce_grads(kd_params)          # atts_q / embed_s are not under DDP (fixes Q7)
+            trainer.finish_grad_sync()                  # atts_q / embed_s are not under DDP (fixes Q7)
         if scaler is not None:
             scaler.step(optimizer)
             scaler.update()

@@ -11,6 +11,8 @@
 """
 from __future__ import print_function
 
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -22,7 +24,10 @@ from .util import accuracy
 class ContrastTrainer(BaseTrainer):
     """trainer for contrastive distillation"""
 
-    _ema_tables = {}
+    # device pointer tables of the (model, model_ema) pairs seen, newest last; bounded (a trainer touches two pairs:
+    # backbone and mlp head) so that short-lived models -- tests, sweeps -- do not pile up tables keyed by dead ids
+    _ema_tables = collections.OrderedDict()
+    _EMA_TABLES_MAX = 8
 
     def __init__(self, args):
         super().__init__(args)
@@ -37,10 +42,15 @@ class ContrastTrainer(BaseTrainer):
         ps = [p.detach() for p in model.parameters()]
         es = [p.detach() for p in model_ema.parameters()]
         key = (id(model), id(model_ema))
-        tab = ContrastTrainer._ema_tables.get(key)
-        if tab is None or not tab.matches(ps, es):
+        tabs = ContrastTrainer._ema_tables
+        tab = tabs.get(key)
+        if tab is None or not tab.matches(ps, es):       # (matches() also catches an id reused by a new model)
             tab = ops.EmaTable(ps, es)
-            ContrastTrainer._ema_tables[key] = tab
+            tabs[key] = tab
+            while len(tabs) > ContrastTrainer._EMA_TABLES_MAX:
+                tabs.popitem(last=False)
+        else:
+            tabs.move_to_end(key)
         ops.ema_update_(tab, m)
 
     # -- collectives ------------------------------------------------------------------------------
@@ -66,13 +76,21 @@ class ContrastTrainer(BaseTrainer):
         if mode == "gather" and dist.is_available() and dist.is_initialized():
             return self._shuffle_bn_gather(x, model_ema, model_ema_head)
         bsz = x.size(0)
-        shuffle_ids = torch.randperm(bsz).to(x.device)          # host RNG stream, as the reference (:108)
+        shuffle_ids = self._host_randperm(bsz, x.device)        # host RNG stream, as the reference (:108)
         reverse_ids = torch.argsort(shuffle_ids)
         with torch.no_grad():
             feat_t, _ = model_ema(x[shuffle_ids], is_feat=True)
             all_k = model_ema_head(feat_t[-1])
         k = all_k[reverse_ids]
         return k, all_k
+
+    @staticmethod
+    def _host_randperm(n, device):
+        """torch.randperm from the HOST generator (the reference's stream: seeded runs draw identical permutations), moved
+        through pinned memory without blocking -- a pageable H2D copy is a host-device sync every step."""
+        if device.type != "cuda":
+            return torch.randperm(n).to(device)
+        return torch.randperm(n, pin_memory=True).to(device, non_blocking=True)
 
     def _shuffle_bn_gather(self, x, model_ema, model_ema_head):
         args = self.args
@@ -81,7 +99,7 @@ class ContrastTrainer(BaseTrainer):
         node_x = [torch.ones_like(x) for _ in range(dist.get_world_size(gp))]
         dist.all_gather(node_x, x.contiguous(), group=gp, async_op=False)
         node_x = torch.cat(node_x, dim=0)
-        shuffle_ids = torch.randperm(bsz * dist.get_world_size(gp)).to(x.device)
+        shuffle_ids = self._host_randperm(bsz * dist.get_world_size(gp), x.device)
         reverse_ids = torch.argsort(shuffle_ids)
         dist.broadcast(shuffle_ids, 0)
         dist.broadcast(reverse_ids, 0)
@@ -107,14 +125,14 @@ class ContrastTrainer(BaseTrainer):
             node_x = [torch.ones_like(x) for _ in range(dist.get_world_size(gp))]
             dist.all_gather(node_x, x.contiguous(), group=gp, async_op=False)
             node_x = torch.cat(node_x, dim=0)
-            shuffle_ids = torch.randperm(bsz * dist.get_world_size(gp)).to(x.device)
+            shuffle_ids = self._host_randperm(bsz * dist.get_world_size(gp), x.device)
             reverse_ids = torch.argsort(shuffle_ids)
             dist.broadcast(shuffle_ids, 0)
             dist.broadcast(reverse_ids, 0)
             lo = args.local_rank * bsz
         else:
             node_x = x
-            shuffle_ids = torch.randperm(bsz).to(x.device)
+            shuffle_ids = self._host_randperm(bsz, x.device)
             reverse_ids = torch.argsort(shuffle_ids)
             lo = 0
         with torch.no_grad():
@@ -144,8 +162,56 @@ class ContrastTrainer(BaseTrainer):
         return losses, accuracies
 
     # -- DP: keep the trainable criterion modules (atts_q, embed_s) in sync across ranks (fixes Q7) --
+    # They are not under DDP (their forward is called module by module), so their gradients get ONE flat all-reduce per
+    # step, launched from autograd hooks the moment the last of them is accumulated -- these modules sit at the top of the
+    # graph, so the collective overlaps the whole backbone backward -- and waited for right before optimizer.step().
+    def attach_grad_sync(self, params):
+        """Register the hooks once per parameter list (no-op without a process group or at world size 1)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        params = [p for p in params if p.requires_grad]
+        if getattr(self, "_gs_params", None) is not None and [id(p) for p in self._gs_params] == [id(p) for p in params]:
+            return
+        for h in getattr(self, "_gs_handles", []):
+            h.remove()
+        self._gs_params, self._gs_seen, self._gs_work, self._gs_flat = params, 0, None, None
+        # how many of them receive a gradient per backward: learnt from the first step (atts_k / atts_queue / embed_t are
+        # in the list but never get one -- SURVEY Q6), until then the blocking fallback in finish_grad_sync() serves
+        self._gs_expect = len(params)
+
+        def hook(_p):
+            self._gs_seen += 1
+            if self._gs_seen == self._gs_expect:                # every criterion gradient of this backward is there
+                self._launch_grad_sync()
+        self._gs_handles = [p.register_post_accumulate_grad_hook(hook) for p in params]
+
+    def _launch_grad_sync(self):
+        grads = [p.grad for p in self._gs_params if p.grad is not None]
+        if not grads:
+            return
+        self._gs_grads = grads
+        self._gs_flat = torch.cat([g.reshape(-1) for g in grads])
+        self._gs_work = dist.all_reduce(self._gs_flat, async_op=True)
+
+    def finish_grad_sync(self):
+        """Wait for the step's criterion all-reduce (launching it now if the hooks did not see every gradient, e.g. a
+        module that took no part in this step's graph), average, and scatter back into the .grad tensors."""
+        if getattr(self, "_gs_params", None) is None:
+            return
+        if self._gs_work is None:
+            if self._gs_seen > 0:
+                self._gs_expect = self._gs_seen                 # from the next step on the hooks launch it early
+            self._launch_grad_sync()
+        if self._gs_work is not None:
+            self._gs_work.wait()
+            flat = self._gs_flat.div_(dist.get_world_size())
+            torch._foreach_copy_(self._gs_grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in self._gs_grads]),
+                                                                               self._gs_grads)])
+        self._gs_seen, self._gs_work, self._gs_flat = 0, None, None
+
     @staticmethod
     def allreduce_grads(params):
+        """Blocking form of the same reduction (kept for callers without hooks)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         grads = [p.grad for p in params if p.grad is not None]
@@ -154,8 +220,4 @@ class ContrastTrainer(BaseTrainer):
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat)
         flat.div_(dist.get_world_size())
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])

@@ -87,7 +87,7 @@ def build_parser():
     p.add_argument("--nce_t", default=0.07, type=float)
     p.add_argument("--nce_m", default=0.5, type=float)
     p.add_argument("--alpha", default=0.999, type=float)
-    p.add_argument("--mem", default="MoCo", type=str, choices=["MoCo", "MoCoST", "MoCoSSTT"])
+    p.add_argument("--mem", default="MoCo", type=str, choices=["MoCo", "MoCoST", "MoCoSSTT", "MoCoAtt"])   # (+MoCoAtt)
     p.add_argument("--head", default="None", type=str, choices=["None", "linear", "mlp"])
     # distill option
     p.add_argument("--weight", type=float, default=1e-4)
@@ -206,12 +206,33 @@ def build_training(opt, device):
     return model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer
 
 
+def _rank_state_path(folder, rank):
+    return os.path.join(folder, "ckpt_last_rank{}.pth".format(int(rank)))
+
+
+def _get_rng_state(device):
+    return {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
+            "cuda": torch.cuda.get_rng_state(device) if device.type == "cuda" else None}
+
+
+def _set_rng_state(st, device):
+    random.setstate(st["python"])
+    np.random.set_state(st["numpy"])
+    torch.set_rng_state(st["torch"].cpu())
+    if st.get("cuda") is not None and device.type == "cuda":
+        torch.cuda.set_rng_state(st["cuda"].cpu(), device)
+
+
 def main_worker(gpu, ngpus_per_node, opt):
     opt.gpu = int(gpu)
     opt.gpu_id = int(gpu)
-    opt.rank = int(os.environ.get("NODE_RANK", 0))
-    opt.dist_backend = "nccl"                                    # RCCL on ROCm (reference :232)
-    if not torch.cuda.is_available():
+    # node rank: torchrun exports GROUP_RANK (NODE_RANK is the older launcher's name); single node -> 0
+    opt.rank = int(os.environ.get("GROUP_RANK", os.environ.get("NODE_RANK", 0)))
+    opt.dist_backend = os.environ.get("MOMA_DIST_BACKEND", "nccl")      # 'nccl' = RCCL on ROCm (reference :232)
+    # MOMA_HOST_TEST_CPU=1 lets the HOST logic (process group, DDP wrap, epoch loop, checkpoints) run in CPU-only tests that
+    # replace the kernel wrappers by stand-ins; the product itself has no CPU path: without stand-ins the first kernel call raises
+    host_test = os.environ.get("MOMA_HOST_TEST_CPU") == "1"
+    if not torch.cuda.is_available() and not host_test:
         raise RuntimeError("train_student_moma: no GPU visible. The MoMA hot path is a HIP library for gfx950 "
                            "and has no CPU fallback.")
     trainer = ContrastTrainer(opt)
@@ -221,14 +242,16 @@ def main_worker(gpu, ngpus_per_node, opt):
         torch.manual_seed(opt.seed)
         np.random.seed(opt.seed)
     torch.backends.cudnn.benchmark = opt.miopen_find == "on"          # reference :418 sets it unconditionally
-    device = torch.device("cuda", opt.gpu)
+    device = torch.device("cuda", opt.gpu) if torch.cuda.is_available() else torch.device("cpu")
+    opt.device = device
     print("opt.n_cls: ", opt.n_cls)
 
     model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer = build_training(opt, device)
     if contrast is not None:
         trainer.broadcast_memory(contrast)                       # optional step: synchronize memory (:336)
     if opt.multiprocessing_distributed:
-        ddp_s = torch.nn.parallel.DistributedDataParallel(model_s, device_ids=[opt.gpu], gradient_as_bucket_view=True)
+        ddp_s = torch.nn.parallel.DistributedDataParallel(model_s, device_ids=[opt.gpu] if device.type == "cuda" else None,
+                                                          gradient_as_bucket_view=True)
         module_list = [ddp_s] + [m for m in list(module_list)[1:]]
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")
@@ -245,23 +268,32 @@ def main_worker(gpu, ngpus_per_node, opt):
     best_acc, best_f1, t_total = 0.0, 0.0, time.time()
     start_epoch = 1
     if opt.resume:
-        ck = torch.load(opt.resume, map_location=device)
+        ck = torch.load(opt.resume, map_location=device, weights_only=False)
         model_s.load_state_dict(ck["model"])
         model_t.load_state_dict(ck["model_t"])
         criterion_list[2].load_state_dict(ck["criterion_kd"])
-        if contrast is not None and ck.get("contrast") is not None:
-            contrast.load_state_dict(ck["contrast"])
         optimizer.load_state_dict(ck["optimizer"])
+        # per-rank state (the queue and its pointer are per rank in the default per_rank mode, and so are the RNG streams)
+        # sits next to the shared file; a run resumed on fewer / other ranks falls back to rank 0's queue
+        mine = _rank_state_path(os.path.dirname(opt.resume), opt.rank)
+        rs = torch.load(mine, map_location=device, weights_only=False) if os.path.isfile(mine) else None
+        if contrast is not None:
+            qstate = (rs or {}).get("contrast") or ck.get("contrast")
+            if qstate is not None:
+                contrast.load_state_dict(qstate)
+        if rs is not None and rs.get("rng") is not None:
+            _set_rng_state(rs["rng"], device)
         best_acc, best_f1, start_epoch = ck.get("best_acc", 0.0), ck.get("best_f1", 0.0), ck["epoch"] + 1
-        print("==> resumed from {} (epoch {}, queue pointer {})".format(
-            opt.resume, ck["epoch"], contrast.index if contrast is not None else "-"))
+        print("==> resumed from {} (epoch {}, queue pointer {}, per-rank state {})".format(
+            opt.resume, ck["epoch"], contrast.index if contrast is not None else "-", "found" if rs else "absent"))
     for epoch in range(start_epoch, opt.epochs + 1):
         adjust_learning_rate(epoch, opt, optimizer)
         print("==> training...")
         t1 = time.time()
         train_acc, train_loss = train_distill_moma(epoch, train_loader, module_list, criterion_list,
                                                    trainer if opt.distill == "moma" else None, contrast, optimizer, opt)
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
         t2 = time.time()
         if opt.multiprocessing_distributed:
             metrics = torch.tensor([train_acc, train_loss], device=device)
@@ -295,12 +327,16 @@ def main_worker(gpu, ngpus_per_node, opt):
             if test_stat is not None:
                 metrics.update(test_cf=test_stat["conf_mat"].tolist(), test_loss=test_loss, test_acc=test_acc)
             update_dict_to_json(epoch, metrics, os.path.join(opt.save_folder, "stat.json"))
-            # full training state (the reference saves the student only): enough to resume bit-for-bit
+            # full training state (the reference saves the student only): shared part by the main rank ...
             torch.save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
                         "criterion_kd": criterion_list[2].state_dict(),
                         "contrast": contrast.state_dict() if contrast is not None else None,
                         "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1},
                        os.path.join(opt.save_folder, "ckpt_last.pth"))
+        # ... and the per-rank part (queue + pointer of THIS rank, RNG streams) by every rank
+        os.makedirs(opt.save_folder, exist_ok=True)
+        torch.save({"epoch": epoch, "contrast": contrast.state_dict() if contrast is not None else None,
+                    "rng": _get_rng_state(device)}, _rank_state_path(opt.save_folder, opt.rank))
     if is_main:
         print("best accuracy:", best_acc)
         save_state = {k: v for k, v in vars(opt).items() if not k.startswith("_") and k != "trace"}

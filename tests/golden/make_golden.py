@@ -14,6 +14,7 @@ What is captured:
   G5 step trace  helper/loops_moma.py:221-373         10 steps of train_distill_moma (resnet8 pair)
   G6 dual queue  MoMA/mem_moco.py:165-253             MoCoST / MoCoSSTT logits, queues, pointer
   G7 MoCoAtt     MoMA/mem_moco.py:103-161             cross-attention variants: logits, dq, queue
+  G5b step trace helper/loops_moma.py:221-373         the same loop at K = 65536, --head mlp, d in {128, 512}
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -339,10 +340,139 @@ def g5_step_trace():
     np.savez_compressed(os.path.join(OUT, "g5_step_trace.npz"), **out)
 
 
+def seeded_uniform_(t, gen, bound):
+    """t <- U(-bound, bound) from a dedicated generator (reproducible in the tests without shipping the tensor)."""
+    with torch.no_grad():
+        t.copy_((torch.rand(t.shape, generator=gen) * 2 - 1) * bound)
+
+
+def g5b_step_trace_big():
+    """The loop at the sizes the benchmark's kernels run at: K = 65536, --head mlp, feat_dim in {128, 512}, resnet8 pair,
+    B = 8, 10 steps.  The big tensors (queue 65536 x d, attention weights) are NOT stored: they are drawn from dedicated
+    seeded generators (same distribution as the reference's default init: normalised randn rows / U(-1/sqrt(fan_in), ..))
+    that the tests re-run; stored are the small weights, per-step total loss AND per-step loss_kd, the pointer trace,
+    the enqueued rows of the final queue and a few checksums."""
+    import argparse
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import helper.loops_moma as L
+    from models.resnet import resnet8
+    from MoMA.mem_moco import build_mem
+    from MoMA.criterion_moco_att import CMO
+    from learning.contrast_trainer import ContrastTrainer
+    from distiller_zoo import DistillKL
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.set_num_threads(8)
+    out = {}
+    K = 65536
+    cases = [(128, 0.05), (512, 0.05), (512, 0.002)]          # (feat_dim, lr): at lr 0.05 loss_kd collapses to 0 within 4 steps
+    for ci, (feat_dim, lr) in enumerate(cases):
+        opt = argparse.Namespace(
+            distill="moma", head="mlp", feat_dim=feat_dim, attn="self", mem="MoCo", nce_k=K, nce_t=0.15,
+            alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=None, multiprocessing_distributed=True,
+            print_freq=1000, batch_size=8, local_rank=0, node_rank=0, ngpus_per_node=1, rank=0, world_size=1)
+        torch.manual_seed(5100 + ci)
+        model_s = resnet8(num_classes=100)
+        model_t = resnet8(num_classes=100)
+        opt.s_dim = opt.t_dim = 64
+        contrast = build_mem(opt)
+        criterion_kd = CMO(opt)
+        # big tensors from dedicated generators (re-drawn by the tests)
+        gq = torch.Generator().manual_seed(5200 + ci)
+        with torch.no_grad():
+            contrast.memory.copy_(torch.nn.functional.normalize(torch.randn(K, feat_dim, generator=gq)))
+        gw = torch.Generator().manual_seed(5300 + ci)
+        for name in ("atts_q", "atts_k", "atts_queue"):
+            att = getattr(criterion_kd, name)
+            for lin in (att.qkv, att.proj):
+                b = 1.0 / np.sqrt(lin.in_features)
+                seeded_uniform_(lin.weight, gw, b)
+                seeded_uniform_(lin.bias, gw, b)
+        p = f"c{ci}_"
+        out[p + "feat_dim"] = np.array(feat_dim)
+        out[p + "seeds"] = np.array([5200 + ci, 5300 + ci])
+        trainer = ContrastTrainer(opt)
+        trainer.local_group = dist.new_group([0])
+        trainable = nn.ModuleList([model_s, criterion_kd.atts_q, criterion_kd.atts_k, criterion_kd.atts_queue,
+                                   criterion_kd.embed_s])
+        optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+        out[p + "lr"] = np.array(lr)
+        for name, t in model_s.state_dict().items():
+            out[p + "s." + name] = t.numpy().copy()
+        for name, t in model_t.state_dict().items():
+            out[p + "t." + name] = t.numpy().copy()
+        for name, t in criterion_kd.state_dict().items():
+            if name.startswith("embed_"):
+                out[p + "kd." + name] = t.numpy().copy()
+        out[p + "memory0_sum"] = np.array(contrast.memory.double().sum().item())
+        out[p + "memory0_row7"] = contrast.memory[7].numpy().copy()
+        out[p + "attsq_qkv_w_sum"] = np.array(criterion_kd.atts_q.qkv.weight.double().sum().item())
+        ddp_s = DDP(model_s)
+        mods = nn.ModuleList([ddp_s, model_t])
+        crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(opt.kd_T), criterion_kd])
+        steps_per_epoch, epochs = 5, 2
+        g = torch.Generator().manual_seed(787 + ci)
+        images = torch.randn(steps_per_epoch * epochs, 8, 3, 32, 32, generator=g)
+        labels = torch.randint(0, 100, (steps_per_epoch * epochs, 8), generator=g)
+        out[p + "data_seed"] = np.array(787 + ci)
+        rec = {"loss": [], "loss_kd": [], "index": []}
+        orig_update = L.AverageMeter.update
+        calls = {"n": 0}
+
+        def upd(self, val, n=1):
+            if calls["n"] % 3 == 0:
+                rec["loss"].append(val)
+            calls["n"] += 1
+            return orig_update(self, val, n)
+
+        orig_cla = ContrastTrainer._compute_loss_accuracy
+
+        def cla(logits, target, criterion):          # helper/loops_moma.py:332-335 -> the step's loss_kd
+            losses, accs = orig_cla(logits=logits, target=target, criterion=criterion)
+            rec["loss_kd"].append(float(losses[0].item()))
+            return losses, accs
+
+        L.AverageMeter.update = upd
+        trainer._compute_loss_accuracy = cla
+        torch.manual_seed(9100 + ci)
+        out[p + "loop_seed"] = np.array(9100 + ci)
+        try:
+            for ep in range(epochs):
+                loader = [(images[ep * steps_per_epoch + i], labels[ep * steps_per_epoch + i])
+                          for i in range(steps_per_epoch)]
+
+                def gen():
+                    for it in loader:
+                        yield it
+                        rec["index"].append(contrast.index)
+
+                class LL:
+                    def __len__(self): return steps_per_epoch
+                    def __iter__(self): return gen()
+                L.train_distill_moma(ep + 1, LL(), mods, crits, trainer, contrast, optimizer, opt)
+        finally:
+            L.AverageMeter.update = orig_update
+        out[p + "loss"] = np.array(rec["loss"], dtype=np.float64)
+        out[p + "loss_kd"] = np.array(rec["loss_kd"], dtype=np.float64)
+        out[p + "index"] = np.array(rec["index"], dtype=np.int64)
+        out[p + "memory_rows_final"] = contrast.memory[:80].numpy().copy()        # the 10 x 8 enqueued rows
+        out[p + "memory_final_sum"] = np.array(contrast.memory.double().sum().item())
+        out[p + "kd_final.atts_q.proj.weight_8x8"] = criterion_kd.atts_q.proj.weight.detach()[:8, :8].numpy().copy()
+        out[p + "kd_final.atts_q.qkv.bias_16"] = criterion_kd.atts_q.qkv.bias.detach()[:16].numpy().copy()
+        out[p + "t_final.fc.weight"] = model_t.state_dict()["fc.weight"].numpy().copy()
+        out[p + "s_final.fc.weight"] = model_s.state_dict()["fc.weight"].numpy().copy()
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "g5b_step_trace_big.npz"), **out)
+
+
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
@@ -350,6 +480,7 @@ if __name__ == "__main__":
     if "g5" in which: g5_step_trace()
     if "g6" in which: g6_dual_queue()
     if "g7" in which: g7_mocoatt()
+    if "g5b" in which: g5b_step_trace_big()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

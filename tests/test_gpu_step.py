@@ -78,3 +78,124 @@ def test_loop_matches_reference_trace(golden_dir, ci, fused, overlap):
     np.testing.assert_allclose(mt.fc.weight.detach().cpu().numpy(), g[p + "t_final.fc.weight"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(kd.atts_q.proj.weight.detach().cpu().numpy(), g[p + "kd_final.atts_q.proj.weight"],
                                rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+@pytest.mark.parametrize("queue_dtype,overlap", [("fp32", True), ("bf16", True), ("bf16", False)])
+def test_loop_bf16_policy_matches_reference_trace_big_queue(golden_dir, ci, queue_dtype, overlap):
+    """The configuration the benchmark times, tied to the reference at LOOP level (G5b: K = 65536, --head mlp, d = 128 /
+    512): moma_prec = bf16 -> the one-pass K2 (infonce_flash_kernel), the fused K1 core forward + backward, K3 on the queue
+    (fp32 storage + bf16 mirror, or bf16 storage), K4; teacher side on the second stream and replayed from HIP graphs when
+    overlap is on.  Backbone (resnet8) stays fp32 so the comparison isolates the KD kernels.
+    Tolerances: per-step loss_kd within 1e-3 relative of the reference (north star; the lr = 0.05 cases collapse to
+    loss_kd = 0 by step 4, there 1e-3 absolute), total loss 5e-3, pointer exact, final queue rows equal after bf16 rounding."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.g5b_util import K_BIG, batches, big_queue, fill_attention_, sd
+    from moma_amd.backbones.resnet_cifar import resnet8
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.distiller_zoo import DistillKL
+    from moma_amd import _lib
+
+    torch.backends.cudnn.benchmark = False
+    g = np.load(os.path.join(golden_dir, "g5b_step_trace_big.npz"))
+    p = f"c{ci}_"
+    d = int(g[p + "feat_dim"])
+    lr = float(g[p + "lr"])
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K_BIG, nce_t=0.15,
+                             alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False,
+                             print_freq=1000, batch_size=8, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16",
+                             queue_dtype=queue_dtype, moma_fused=True, trace=[], overlap_teacher=overlap,
+                             graph_teacher=overlap)
+    assert _lib.load().moma_infonce_fused_workspace_bytes(8, d, K_BIG, 1, 1) > 0
+    dev = torch.device("cuda", 0)
+    ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
+    ms.load_state_dict(sd(g, p + "s.")); mt.load_state_dict(sd(g, p + "t."))
+    contrast = build_mem(opt)
+    contrast.memory.copy_(big_queue(g, p, d).to(contrast.memory.dtype))
+    kd = CMO(opt)
+    fill_attention_(kd, g, p)
+    ms, mt, contrast, kd = ms.to(dev), mt.to(dev), contrast.to(dev), kd.to(dev)
+    trainer = ContrastTrainer(opt)
+    trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+    optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    mods = nn.ModuleList([ms, mt])
+    crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(opt.kd_T), kd])
+    images, labels = batches(g, p)
+    torch.manual_seed(int(g[p + "loop_seed"]))
+    for ep in range(2):
+        loader = [(images[ep * 5 + i], labels[ep * 5 + i]) for i in range(5)]
+        train_distill_moma(ep + 1, loader, mods, crits, trainer, contrast, optimizer, opt)
+    losses = np.array([float(t[0]) for t in opt.trace])
+    kds = np.array([float(t[2]) for t in opt.trace])
+    assert [t[1] for t in opt.trace] == [int(v) for v in g[p + "index"]]
+    ref_kd, ref_loss = g[p + "loss_kd"], g[p + "loss"]
+    print("loss_kd |err|:", np.abs(kds - ref_kd).round(5), " total |err|:", np.abs(losses - ref_loss).round(5))
+    np.testing.assert_allclose(kds, ref_kd, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(losses, ref_loss, rtol=1e-3, atol=5e-3)
+    rows = contrast.memory[:80].float().cpu().numpy()
+    ref_rows = g[p + "memory_rows_final"]
+    # enqueued keys went through bf16 arithmetic (attention module) and, with a bf16 queue, bf16 storage
+    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
+    if contrast.memory.dtype == torch.float32:            # the mirror holds exactly the bf16 rounding of the fp32 queue
+        assert torch.equal(contrast._shadow[:80], contrast.memory[:80].to(torch.bfloat16))
+        assert torch.equal(contrast._shadow[80:4096], contrast.memory[80:4096].to(torch.bfloat16))
+    assert all(q.grad is None for q in kd.atts_k.parameters()) and all(q.grad is None for q in kd.atts_queue.parameters())
+    np.testing.assert_allclose(kd.atts_q.proj.weight.detach()[:8, :8].cpu().numpy(), g[p + "kd_final.atts_q.proj.weight_8x8"],
+                               rtol=0, atol=2e-3)
+
+
+def test_shuffle_bn_gather_mode_single_rank_equals_per_rank(golden_dir):
+    """`--shuffle_bn gather` (the reference's collectives C3-C5: image all_gather, id broadcast, key all_gather; reference
+    learning/contrast_trainer.py:90-133) on a one-rank RCCL process group must reproduce the per-rank mode bit for bit:
+    same permutation stream, same keys, same queue.  Runs the real collectives on the GPU (backend 'nccl' = RCCL)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.distributed as dist
+    from moma_amd.backbones.resnet_cifar import resnet8
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.distiller_zoo import DistillKL
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.backends.cudnn.benchmark = False
+        results = {}
+        for mode in ("per_rank", "gather"):
+            opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=128, attn="self", mem="MoCo", nce_k=4096, nce_t=0.15,
+                                     alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=True,
+                                     print_freq=1000, batch_size=16, rank=0, local_rank=0, node_rank=0, ngpus_per_node=1,
+                                     world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16", moma_fused=True,
+                                     trace=[], overlap_teacher=False, graph_teacher=False, shuffle_bn=mode)
+            torch.manual_seed(0)
+            ms, mt = resnet8(num_classes=10).to(dev), resnet8(num_classes=10).to(dev)
+            contrast = build_mem(opt).to(dev)
+            kd = CMO(opt).to(dev)
+            trainer = ContrastTrainer(opt)
+            trainer.local_group = dist.new_group([0])
+            trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+            optimizer = torch.optim.SGD(trainable.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+            crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
+            g = torch.Generator().manual_seed(5)
+            loader = [(torch.randn(16, 3, 32, 32, generator=g), torch.randint(0, 10, (16,), generator=g)) for _ in range(4)]
+            torch.manual_seed(77)
+            train_distill_moma(1, loader, nn.ModuleList([ms, mt]), crits, trainer, contrast, optimizer, opt)
+            results[mode] = (torch.stack([t[0] for t in opt.trace]).cpu(), contrast.memory.clone().cpu(), contrast.index,
+                             kd.atts_q.proj.weight.detach().clone().cpu())
+        a, b = results["per_rank"], results["gather"]
+        assert a[2] == b[2] == 64
+        assert torch.equal(a[1], b[1])                  # same keys enqueued in the same (shuffled) order
+        assert torch.allclose(a[0], b[0], rtol=0, atol=1e-5) and torch.allclose(a[3], b[3], rtol=0, atol=1e-6)
+    finally:
+        if own_pg:
+            dist.destroy_process_group()

@@ -60,3 +60,35 @@ def test_step_trace_matches_reference(golden_dir, ci):
                                rtol=1e-4, atol=1e-5)
     # atts_k is in the optimizer but never gets a gradient -> not even weight decay touches it
     assert np.array_equal(cmo.atts_k.proj.weight.detach().numpy(), g[p + "kd_final.atts_k.proj.weight"])
+
+
+def test_step_trace_big_queue_matches_reference(golden_dir):
+    """The same loop at the benchmark's KD sizes (K = 65536, --head mlp, d = 512; G5b, lr 0.002 case): per-step total
+    loss AND per-step loss_kd, pointer, the enqueued rows of the final queue."""
+    from tests.g5b_util import K_BIG, batches, big_queue, fill_attention_, sd
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "g5b_step_trace_big.npz"))
+    ci = 2
+    p = f"c{ci}_"
+    d = int(g[p + "feat_dim"])
+    ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
+    ms.load_state_dict(sd(g, p + "s.")); mt.load_state_dict(sd(g, p + "t."))
+    cmo = OracleCMO("mlp", 64, 64, d)
+    fill_attention_(cmo, g, p)
+    contrast = OracleMoCo(d, K_BIG, 0.15)
+    contrast.memory.copy_(big_queue(g, p, d))
+    run = StepOracle(ms, mt, cmo, contrast, head="mlp", lr=float(g[p + "lr"]))
+    images, labels = batches(g, p)
+    torch.manual_seed(int(g[p + "loop_seed"]))
+    losses, kds, idxs = [], [], []
+    for ep in range(2):
+        run.start_epoch()
+        for i in range(5):
+            loss, _, kd = run.step(images[ep * 5 + i], labels[ep * 5 + i])
+            losses.append(loss); kds.append(kd); idxs.append(contrast.index)
+    assert idxs == [int(v) for v in g[p + "index"]]
+    np.testing.assert_allclose(losses, g[p + "loss"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(kds, g[p + "loss_kd"], rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(contrast.memory[:80].numpy(), g[p + "memory_rows_final"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cmo.atts_q.proj.weight.detach()[:8, :8].numpy(), g[p + "kd_final.atts_q.proj.weight_8x8"],
+                               rtol=1e-4, atol=1e-6)
