@@ -55,6 +55,8 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         dev = torch.device("cuda", opt.gpu if (opt.gpu is not None and opt.multiprocessing_distributed) else 0) \
             if torch.cuda.is_available() else torch.device("cpu")
     ema_ok = None
+    mocoatt = getattr(opt, "mem", "MoCo") == "MoCoAtt"
+    attn_in_shuffle = opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix") and not mocoatt
     if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
         # one flat all-reduce per step for the trainable criterion modules, launched from autograd hooks (overlaps backward)
         trainer.attach_grad_sync([p for p in criterion_kd.parameters() if p.requires_grad])
@@ -110,10 +112,12 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                     if _same_arch(criterion_kd.embed_s, criterion_kd.embed_t):
                         trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
             model_t.apply(_set_bn_train)                                                  # (:314-318)
+            if attn_in_shuffle:         # key encoding + attention need the student's query: done on the main stream below
+                return lt.float(), None, None
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 kk, akk = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
             kk, akk = kk.float(), akk.float()
-            if opt.attn == "self":                                                        # K1, key side (:327-329)
+            if opt.attn == "self" and not mocoatt:                                        # K1, key side (:327-329)
                 with torch.no_grad():
                     kk = criterion_kd.atts_k(kk)
                     akk = criterion_kd.atts_queue(akk)
@@ -146,10 +150,27 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
                 f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
             f_s = f_s.float()
-            if opt.attn == "self":                                                        # K1, query side (:326)
+            if attn_in_shuffle:
+                # attn in {self_mix, self_nomix}: Shuffle-BN key encoding with the attention applied before the un-shuffle,
+                # over [q ; k] or per side (reference learning/contrast_trainer.py:135-187; train_student_moma.py:345-352
+                # registers these modules as trainable -- the reference loop never reaches the call)
+                with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+                    f_s, k, all_k = trainer._shuffle_bn_attn(images, teacher, criterion_kd.embed_t, criterion_kd, f_s)
+                f_s, k, all_k = f_s.float(), k.float(), all_k.float()
+            elif opt.attn == "self" and not mocoatt:                                      # K1, query side (:326)
                 f_s = criterion_kd.atts_q(f_s)
 
-            if fused:                                                                     # K2 + K3
+            if mocoatt:
+                # --mem MoCoAtt: the memory applies the teacher-student cross-attention variant itself
+                # (reference MoMA/mem_moco.py:111-161); materialised logits -> CrossEntropy as in :331-335
+                if opt.attn == "dual2":
+                    raise NotImplementedError("attn='dual2' yields positive logits only ([B]); the reference's CrossEntropy "
+                                              "over them is undefined (MoMA/mem_moco.py:51-66,148-149)")
+                criterion = nn.CrossEntropyLoss()
+                output = contrast(q=f_s, k=k, all_k=all_k, attn=opt.attn, criterion_kd=criterion_kd)
+                c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
+                loss_kd = c_losses[0]
+            elif fused:                                                                   # K2 + K3
                 loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k)
             else:                                                                         # reference sequence (:331-335)
                 criterion = nn.CrossEntropyLoss()

@@ -149,7 +149,7 @@ class ContrastTrainer(BaseTrainer):
             node_id, ngpus = args.node_rank, args.ngpus_per_node
             node_k = all_k[node_id * ngpus * bsz:(node_id + 1) * ngpus * bsz]
         else:
-            all_k = node_k = k
+            all_k = node_k = k.detach()         # (the reference's keys come out of an all_gather: no gradient, only q has one)
         k = node_k[reverse_ids[lo:lo + bsz]]
         return q, k, all_k
 

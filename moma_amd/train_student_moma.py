@@ -180,18 +180,11 @@ def build_training(opt, device):
             module_list.append(criterion_kd.embed_t)
             trainable_list.append(criterion_kd.embed_s)
             criterion_kd.embed_t.eval()
-        if opt.attn == "self_mix":
-            trainable_list.append(criterion_kd.atts)
-        elif opt.attn == "dual":
-            trainable_list.append(criterion_kd.atts_p)
-            trainable_list.append(criterion_kd.atts_n)
-        elif opt.attn == "self_nomix":
-            trainable_list.append(criterion_kd.atts_q)
-            trainable_list.append(criterion_kd.atts_k)
-        else:
-            trainable_list.append(criterion_kd.atts_q)
-            trainable_list.append(criterion_kd.atts_k)
-            trainable_list.append(criterion_kd.atts_queue)
+        # reference :345-356 lists self_mix / dual / self_nomix / default; the other CMO layouts (all, qk -> `atts`;
+        # dual2 -> atts_p/atts_n; self_qk -> atts_q/atts_k) would hit a missing attribute there and are added by name here
+        for name in ("atts", "atts_p", "atts_n", "atts_q", "atts_k", "atts_queue"):
+            if hasattr(criterion_kd, name):
+                trainable_list.append(getattr(criterion_kd, name))
     else:
         raise NotImplementedError(opt.distill)
     criterion_list = nn.ModuleList([criterion_cls, criterion_div, criterion_kd])

@@ -15,6 +15,7 @@ What is captured:
   G6 dual queue  MoMA/mem_moco.py:165-253             MoCoST / MoCoSSTT logits, queues, pointer
   G7 MoCoAtt     MoMA/mem_moco.py:103-161             cross-attention variants: logits, dq, queue
   G5b step trace helper/loops_moma.py:221-373         the same loop at K = 65536, --head mlp, d in {128, 512}
+  G8 shuffle-BN + attention  learning/contrast_trainer.py:135-187   _shuffle_bn_attn, attn in {self_mix, self_nomix}
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -340,6 +341,58 @@ def g5_step_trace():
     np.savez_compressed(os.path.join(OUT, "g5_step_trace.npz"), **out)
 
 
+def g8_shuffle_bn_attn():
+    """ContrastTrainer._shuffle_bn_attn (learning/contrast_trainer.py:135-187) at world size 1 for attn = 'self_mix' (one
+    module over [q ; k]) and 'self_nomix' (atts_q / atts_k): outputs (q, k, all_k) and the gradients that flow back through
+    the attention into q and into the module weights (the attention runs OUTSIDE no_grad here, on q and on k)."""
+    import argparse
+    import torch.distributed as dist
+    from models.resnet import resnet8
+    from MoMA.criterion_moco_att import CMO
+    from learning.contrast_trainer import ContrastTrainer
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    out = {}
+    B = 12
+    for ci, (attn, head, d) in enumerate([("self_mix", "None", 64), ("self_nomix", "None", 64), ("self_mix", "mlp", 32)]):
+        torch.manual_seed(8000 + ci)
+        opt = argparse.Namespace(head=head, s_dim=64, t_dim=64, feat_dim=d, attn=attn, local_rank=0, node_rank=0,
+                                 ngpus_per_node=1, rank=0, world_size=1)
+        model_t = resnet8(num_classes=10)
+        model_t.train()
+        kd = CMO(opt)
+        trainer = ContrastTrainer(opt)
+        trainer.local_group = dist.new_group([0])
+        x = torch.randn(B, 3, 32, 32)
+        q = torch.nn.functional.normalize(torch.randn(B, d)).requires_grad_(True)
+        w1, w2, w3 = torch.randn(B, d), torch.randn(B, d), torch.randn(B, d)
+        p = f"c{ci}_"
+        out[p + "attn"] = np.array(attn); out[p + "head"] = np.array(head); out[p + "d"] = np.array(d)
+        for name, t in model_t.state_dict().items():
+            out[p + "t." + name] = t.numpy().copy()
+        for name, t in kd.state_dict().items():
+            out[p + "kd." + name] = t.numpy().copy()
+        torch.manual_seed(8100 + ci)                       # the randperm stream
+        out[p + "perm_seed"] = np.array(8100 + ci)
+        q2, k, all_k = trainer._shuffle_bn_attn(x, model_t, kd.embed_t, kd, q)
+        ((q2 * w1).sum() + (k * w2).sum() + (all_k * w3).sum()).backward()
+        out[p + "x"] = x.numpy(); out[p + "q"] = q.detach().numpy()
+        out[p + "w1"] = w1.numpy(); out[p + "w2"] = w2.numpy(); out[p + "w3"] = w3.numpy()
+        out[p + "q_out"] = q2.detach().numpy(); out[p + "k_out"] = k.detach().numpy(); out[p + "all_k"] = all_k.detach().numpy()
+        out[p + "dq"] = q.grad.numpy().copy()
+        for name, prm in kd.named_parameters():
+            if prm.grad is not None:
+                out[p + "grad." + name] = prm.grad.numpy().copy()
+        for name, t in model_t.state_dict().items():       # BN running statistics moved by the train-mode forward
+            if "running_mean" in name:
+                out[p + "t_after." + name] = t.numpy().copy()
+    out["n_cases"] = np.array(3)
+    np.savez_compressed(os.path.join(OUT, "g8_shuffle_bn_attn.npz"), **out)
+
+
 def seeded_uniform_(t, gen, bound):
     """t <- U(-bound, bound) from a dedicated generator (reproducible in the tests without shipping the tensor)."""
     with torch.no_grad():
@@ -472,7 +525,7 @@ def g5b_step_trace_big():
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b", "g8"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
@@ -481,6 +534,7 @@ if __name__ == "__main__":
     if "g6" in which: g6_dual_queue()
     if "g7" in which: g7_mocoatt()
     if "g5b" in which: g5b_step_trace_big()
+    if "g8" in which: g8_shuffle_bn_attn()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -92,3 +92,40 @@ def test_step_trace_big_queue_matches_reference(golden_dir):
     np.testing.assert_allclose(contrast.memory[:80].numpy(), g[p + "memory_rows_final"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(cmo.atts_q.proj.weight.detach()[:8, :8].numpy(), g[p + "kd_final.atts_q.proj.weight_8x8"],
                                rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_shuffle_bn_attn_oracle_matches_reference(golden_dir, ci):
+    """oracle/step_oracle.py:shuffle_bn_attn against the vectors captured from the reference's _shuffle_bn_attn (G8)."""
+    import torch.nn as nn
+    from oracle.step_oracle import OracleAttention, _head, shuffle_bn_attn
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, "g8_shuffle_bn_attn.npz"))
+    p = f"c{ci}_"
+    attn, head, d = str(g[p + "attn"]), str(g[p + "head"]), int(g[p + "d"])
+    mt = resnet8(num_classes=10)
+    mt.load_state_dict(_sd(g, p + "t."))
+    mt.train()
+
+    class C(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed_s, self.embed_t = _head(head, 64, d), _head(head, 64, d)
+            if attn == "self_mix":
+                self.atts = OracleAttention(d)
+            else:
+                self.atts_q, self.atts_k = OracleAttention(d), OracleAttention(d)
+    cmo = C()
+    cmo.load_state_dict(_sd(g, p + "kd."))
+    q = torch.from_numpy(g[p + "q"]).requires_grad_(True)
+    torch.manual_seed(int(g[p + "perm_seed"]))
+    q2, k, all_k = shuffle_bn_attn(torch.from_numpy(g[p + "x"]), mt, cmo.embed_t, cmo, q, attn)
+    ((q2 * torch.from_numpy(g[p + "w1"])).sum() + (k * torch.from_numpy(g[p + "w2"])).sum()
+     + (all_k * torch.from_numpy(g[p + "w3"])).sum()).backward()
+    np.testing.assert_allclose(q2.detach().numpy(), g[p + "q_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(k.detach().numpy(), g[p + "k_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(all_k.detach().numpy(), g[p + "all_k"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q.grad.numpy(), g[p + "dq"], rtol=1e-4, atol=1e-6)
+    for name, prm in cmo.named_parameters():
+        if prm.grad is not None:
+            np.testing.assert_allclose(prm.grad.numpy(), g[p + "grad." + name], rtol=1e-4, atol=1e-5)
