@@ -14,7 +14,8 @@
  *   - every launch function takes the hipStream_t to enqueue on (as void*), is asynchronous on it and
  *     performs no host synchronisation (safe under hipGraph capture);
  *   - return value: 0 = ok, <0 = argument check failed (MOMA_E_*), >0 = hipError_t of a failed launch;
- *     nothing throws; no global mutable state (re-entrant; one host thread per process/GPU);
+ *     nothing throws; no mutable global state apart from a once-per-process kernel-attribute setup behind
+ *     std::call_once (re-entrant; one host thread per process/GPU);
  *   - matrices are row-major and dense unless a leading dimension is given;
  *   - `prec`   : arithmetic of the contractions. MOMA_PREC_F32 = f32-input MFMA (exact fp32 fma chain,
  *                the reference's arithmetic), MOMA_PREC_BF16 = bf16-input MFMA with fp32 accumulate;
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MOMA_ABI_VERSION 1
+#define MOMA_ABI_VERSION 2
 
 enum { MOMA_PREC_F32 = 0, MOMA_PREC_BF16 = 1 };
 enum { MOMA_DT_F32 = 0, MOMA_DT_BF16 = 1 };
@@ -119,20 +120,26 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
  * K1  batch-token multi-head attention -- replaces Attention.forward
  *     (MoMA/criterion_moco_att.py:153-167) and its autograd backward.
  *     x [N,d] -> qkv = x Wqkv^T + bqkv -> per head softmax(q k^T * hd^-1/2) v -> y = a Wproj^T + bproj.
- *     fwd keeps for backward (caller-owned): qkv [N,3d], probs [H,N,N], attn_out [N,d].
+ *     State the forward keeps for the backward (caller-owned): qkv [N,3d], attn_out [N,d] and ONE of
+ *       MOMA_MHA_SAVE_LSE   lse [H,N]     row log-sum-exp of the scaled scores in log2 units -- the fused per-head core
+ *                                         (MOMA_PREC_BF16, head dim a multiple of 16 and <= 128: scores, softmax and context
+ *                                         of :159-163 in ONE launch, flash-style: the backward recomputes P per tile, so no
+ *                                         [H,N,N] array exists at any N; attn = 'all' runs over N = 2B + K tokens);
+ *       MOMA_MHA_SAVE_PROBS probs [H,N,N] the staged path (exact-fp32 policy, other head dims): the reference's op chain.
+ *     moma_mha_saved_state() says which; the other pointer may be NULL (both may be NULL for a forward without backward
+ *     on the fused path, e.g. the no-grad key / queue modules).
  *     bwd writes dx [N,d], dw_qkv [3d,d], db_qkv [3d], dw_proj [d,d], db_proj [d]; any of the five may
- *     be NULL to skip it.  bwd workspace: moma_mha_bwd_workspace_bytes().
- *     With MOMA_PREC_BF16 and a head dim that is a multiple of 16 and <= 128 the per-head core
- *     (scores, softmax, context; :159-163) is ONE fused launch; then `probs` is only needed when a backward
- *     follows and may be NULL (moma_mha_probs_optional() == 1), e.g. for the no-grad key/queue modules.
+ *     be NULL to skip it.  bwd workspace: moma_mha_bwd_workspace_bytes().  No atomics anywhere: results are bitwise
+ *     reproducible run to run.
  * ------------------------------------------------------------------------------------------- */
-int moma_mha_probs_optional(int N, int d, int H, int prec);
+enum { MOMA_MHA_SAVE_PROBS = 0, MOMA_MHA_SAVE_LSE = 1 };
+int moma_mha_saved_state(int N, int d, int H, int prec);
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj,
-                 const float* b_proj, float* y, float* qkv, float* probs, float* attn_out,
+                 const float* b_proj, float* y, float* qkv, float* probs, float* lse, float* attn_out,
                  int N, int d, int H, int prec, moma_stream_t stream);
-size_t moma_mha_bwd_workspace_bytes(int N, int d, int H);
+size_t moma_mha_bwd_workspace_bytes(int N, int d, int H, int prec);
 int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv,
-                 const float* probs, const float* attn_out, const float* dy, float* dx,
+                 const float* probs, const float* lse, const float* attn_out, const float* dy, float* dx,
                  float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj, void* workspace,
                  size_t workspace_bytes, int N, int d, int H, int prec, moma_stream_t stream);
 

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("MOMA_HIP_LIB", os.path.join(_HERE, "lib", "libmoma_hi
 
 PREC_F32, PREC_BF16 = 0, 1
 DT_F32, DT_BF16 = 0, 1
-ABI_VERSION = 1
+MHA_SAVE_PROBS, MHA_SAVE_LSE = 0, 1
+ABI_VERSION = 2
 EMA_BLOCK_ELEMS = 4096
 
 _p = C.c_void_p
@@ -34,8 +35,8 @@ SIGNATURES = {
     "moma_infonce_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
-    "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "moma_mha_probs_optional": (_i, [_i, _i, _i, _i]),
+    "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "moma_mha_saved_state": (_i, [_i, _i, _i, _i]),
     "moma_dwconv_workspace_bytes": (_z, [_i, _i]),
     "moma_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
     "moma_dwconv_bwd_data": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
@@ -46,8 +47,8 @@ SIGNATURES = {
     "moma_bn_workspace_bytes": (_z, [_i]),
     "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i]),
-    "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
 }
 
 _lib = None

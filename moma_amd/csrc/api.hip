@@ -150,8 +150,13 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
     return MOMA_OK;
 }
 
+int moma_mha_saved_state(int N, int d, int H, int prec) {
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0 || bad_prec(prec)) return MOMA_E_SHAPE;
+    return mha_core_fused_supported(N, d, H, prec) ? MOMA_MHA_SAVE_LSE : MOMA_MHA_SAVE_PROBS;
+}
+
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj, const float* b_proj,
-                 float* y, float* qkv, float* probs, float* attn_out, int N, int d, int H, int prec,
+                 float* y, float* qkv, float* probs, float* lse, float* attn_out, int N, int d, int H, int prec,
                  moma_stream_t stream) {
     if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !attn_out) return MOMA_E_NULL;
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
@@ -166,8 +171,8 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
     g.bias = b_qkv;
     MOMA_TRY(launch_gemm(g, st));
     if (fused) {
-        // one launch per module: scores, softmax and context per head (:159-163), mha_fused.hip
-        MOMA_TRY(launch_mha_core_fwd(qkv, attn_out, probs, N, d, H, st));
+        // one launch per module: scores, softmax and context per head (:159-163), mha_fused.hip; keeps lse, never P
+        MOMA_TRY(launch_mha_core_fwd(qkv, attn_out, lse, N, d, H, st));
         g = gemm(attn_out, w_proj, y, N, d, d, d, d, d, 0, 0, 1.f, prec);
         g.bias = b_proj;
         return hip_rc(launch_gemm(g, st));
@@ -187,31 +192,30 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
     return hip_rc(launch_gemm(g, st));
 }
 
-int moma_mha_probs_optional(int N, int d, int H, int prec) {
-    return (N > 0 && d > 0 && H > 0 && d % H == 0 && !bad_prec(prec) && mha_core_fused_supported(N, d, H, prec)) ? 1 : 0;
-}
-
-size_t moma_mha_bwd_workspace_bytes(int N, int d, int H) {
-    if (N <= 0 || d <= 0 || H <= 0) return 0;
-    // dA [N,d] + dP [H,N,N] + dqkv [N,3d]
-    return align_up(((size_t)N * d + (size_t)H * N * N + (size_t)N * 3 * d) * sizeof(float), 256);
+size_t moma_mha_bwd_workspace_bytes(int N, int d, int H, int prec) {
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0 || bad_prec(prec)) return 0;
+    // dA [N,d] + dqkv [N,3d] + (fused: D [H,N] | staged: dP [H,N,N])
+    const size_t mid = mha_core_fused_supported(N, d, H, prec) ? (size_t)H * N : (size_t)H * N * N;
+    return align_up(((size_t)N * d + mid + (size_t)N * 3 * d) * sizeof(float), 256);
 }
 
 int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv, const float* probs,
-                 const float* attn_out, const float* dy, float* dx, float* dw_qkv, float* db_qkv, float* dw_proj,
-                 float* db_proj, void* workspace, size_t workspace_bytes, int N, int d, int H, int prec,
+                 const float* lse, const float* attn_out, const float* dy, float* dx, float* dw_qkv, float* db_qkv,
+                 float* dw_proj, float* db_proj, void* workspace, size_t workspace_bytes, int N, int d, int H, int prec,
                  moma_stream_t stream) {
-    if (!x || !w_qkv || !w_proj || !qkv || !probs || !attn_out || !dy || !workspace) return MOMA_E_NULL;
+    if (!x || !w_qkv || !w_proj || !qkv || !attn_out || !dy || !workspace) return MOMA_E_NULL;
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
     if (bad_prec(prec)) return MOMA_E_DTYPE;
-    if (workspace_bytes < moma_mha_bwd_workspace_bytes(N, d, H)) return MOMA_E_WORKSPACE;
+    const bool fused = mha_core_fused_supported(N, d, H, prec);
+    if (fused ? !lse : !probs) return MOMA_E_NULL;
+    if (workspace_bytes < moma_mha_bwd_workspace_bytes(N, d, H, prec)) return MOMA_E_WORKSPACE;
     if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int hd = d / H;
     const float scale = 1.0f / sqrtf((float)hd);
     float* dA = (float*)workspace;
-    float* dP = dA + (size_t)N * d;
-    float* dqkv = dP + (size_t)H * N * N;
+    float* dP = dA + (size_t)N * d;                                           // fused: the D [H,N] scratch
+    float* dqkv = dP + (fused ? (size_t)H * N : (size_t)H * N * N);
     GemmArgs g;
     // proj: dWproj = dy^T a ; dbproj = colsum(dy) ; dA = dy Wproj
     if (dw_proj) {
@@ -221,27 +225,27 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     if (db_proj) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
     g = gemm(dy, w_proj, dA, N, d, d, d, d, d, 0, 1, 1.f, prec);
     MOMA_TRY(launch_gemm(g, st));
-    if (mha_core_fused_supported(N, d, H, prec)) {
-        // fused per-head backward core: D = rowdot(dA, a) in the dP scratch, then dQ | dK | dV in two launches
-        MOMA_TRY(launch_mha_core_bwd(qkv, probs, attn_out, dA, dP, dqkv, N, d, H, st));
+    if (fused) {
+        // fused per-head backward core from the row log-sum-exp: D = rowdot(dA, a), then dQ | dK | dV in one launch
+        MOMA_TRY(launch_mha_core_bwd(qkv, lse, attn_out, dA, dP, dqkv, N, d, H, st));
     } else {
-    // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
-    g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
-    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-    MOMA_TRY(launch_gemm(g, st));
-    // per head: dP = dA_h V^T
-    g = gemm(dA, qkv + 2 * d, dP, N, N, hd, d, 3L * d, N, 0, 0, 1.f, prec);
-    g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
-    MOMA_TRY(launch_gemm(g, st));
-    // dS = P * (dP - rowsum(dP*P)) * scale   (in place on dP)
-    MOMA_TRY(launch_softmax_bwd_rows(probs, dP, (long)H * N, N, scale, st));
-    // per head: dQ = dS K ; dK = dS^T Q
-    g = gemm(dP, qkv + d, dqkv, N, hd, N, N, 3L * d, 3L * d, 0, 1, 1.f, prec);
-    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-    MOMA_TRY(launch_gemm(g, st));
-    g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
-    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-    MOMA_TRY(launch_gemm(g, st));
+        // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
+        g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
+        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+        MOMA_TRY(launch_gemm(g, st));
+        // per head: dP = dA_h V^T
+        g = gemm(dA, qkv + 2 * d, dP, N, N, hd, d, 3L * d, N, 0, 0, 1.f, prec);
+        g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
+        MOMA_TRY(launch_gemm(g, st));
+        // dS = P * (dP - rowsum(dP*P)) * scale   (in place on dP)
+        MOMA_TRY(launch_softmax_bwd_rows(probs, dP, (long)H * N, N, scale, st));
+        // per head: dQ = dS K ; dK = dS^T Q
+        g = gemm(dP, qkv + d, dqkv, N, hd, N, N, 3L * d, 3L * d, 0, 1, 1.f, prec);
+        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+        MOMA_TRY(launch_gemm(g, st));
+        g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
+        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+        MOMA_TRY(launch_gemm(g, st));
     }
     // qkv linear: dWqkv = dqkv^T x ; dbqkv = colsum(dqkv) ; dx = dqkv Wqkv
     if (dw_qkv) {

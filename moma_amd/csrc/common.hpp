@@ -80,8 +80,8 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 
 // ---- mha_fused.hip (fused per-head attention core, forward) ---------------------------------------
 bool mha_core_fused_supported(int N, int d, int H, int prec);
-hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* probs, int N, int d, int H, hipStream_t st);
-hipError_t launch_mha_core_bwd(const float* qkv, const float* probs, const float* attn_out, const float* dA, float* D,
+hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* lse, int N, int d, int H, hipStream_t st);
+hipError_t launch_mha_core_bwd(const float* qkv, const float* lse, const float* attn_out, const float* dA, float* D,
                                float* dqkv, int N, int d, int H, hipStream_t st);
 
 // ---- bn.hip (BatchNorm2d + activation, NCHW) ------------------------------------------------------

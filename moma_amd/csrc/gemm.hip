@@ -1,8 +1,10 @@
 // Generic batched MFMA GEMM used by the non-fused stages (projection linears, their gradients, the
 // per-head score / context products and the materialised-logits compatibility path).
 //   C[m,n] (+)= alpha * sum_k A(m,k) * B(n,k) + bias[n]
-// 64x64 output tile per 256-thread workgroup (4 waves as 2x2, each wave 2x2 MFMA 16x16 tiles), K in
-// steps of 32 through fp32 LDS tiles.  Two arithmetic policies on the same tiles:
+// TM x TM output tile per 256-thread workgroup, TM = 64 (4 waves as 2x2, each wave 2x2 MFMA 16x16 tiles) or TM = 32 (each
+// wave one 16x16 tile) for problems with few output tiles: the M = 256-class linears of the attention module then cover
+// the chip WITHOUT splitting K, so every result is a fixed-order sum (bitwise reproducible; no atomics).  K in steps of 32
+// through fp32 LDS tiles.  Two arithmetic policies on the same tiles:
 //   MOMA_PREC_F32  : v_mfma_f32_16x16x4_f32  (exact fp32 fma chain = the reference's arithmetic)
 //   MOMA_PREC_BF16 : v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 at fragment load, fp32 accumulate)
 #include "common.hpp"
@@ -10,13 +12,13 @@
 namespace moma {
 
 namespace {
-constexpr int BM = 64, BN = 64, BK = 32, LDK = BK + 4;  // +4 floats: 16-B aligned rows, spreads banks
+constexpr int BK = 32, LDK = BK + 4;  // +4 floats: 16-B aligned rows, spreads banks
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
 
-// One 64 x BK operand tile travels global -> registers -> LDS.  The two halves are split so that the global loads
+// One TM x BK operand tile travels global -> registers -> LDS.  The two halves are split so that the global loads
 // of tile k+1 are in flight while tile k is multiplied (the problems here are M = 256-class: latency-bound, few
 // workgroups, so nothing else hides the ~2 us of a dependent HBM/L2 round trip per k-step).
 //   X(row,k) = trans ? X[k*ld + row] : X[row*ld + k]; out-of-range elements read as zero.
@@ -25,16 +27,18 @@ struct TileRegs {
     float v[8];
 };
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int TM>
 __device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, long ld, int trans, int r0, int rows,
                                           int k0, int kend, int tid) {
+    constexpr int NV = TM / 32;                 // float4 per thread   (TM x 32 elements over 256 threads)
+    constexpr int NS = TM / 8;                  // scalars per thread
     if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             int gr, gk;
             if (!trans) { gr = r0 + (idx >> 3); gk = k0 + (idx & 7) * 4; }          // 4 consecutive k of one row
-            else { gk = k0 + (idx >> 4); gr = r0 + (idx & 15) * 4; }                // 4 consecutive rows of one k
+            else { gk = k0 + idx / (TM / 4); gr = r0 + (idx % (TM / 4)) * 4; }      // 4 consecutive rows of one k
             const long off = trans ? (long)gk * ld + gr : (long)gr * ld + gk;
             const int lim = trans ? rows - gr : kend - gk;                          // valid elements along the vector
             const bool other_ok = trans ? (gk < kend) : (gr < rows);
@@ -50,11 +54,11 @@ __device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, 
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int idx = tid + i * 256;
             int gr, gk;
             if (!trans) { gr = r0 + (idx >> 5); gk = k0 + (idx & 31); }
-            else { gk = k0 + (idx >> 6); gr = r0 + (idx & 63); }
+            else { gk = k0 + idx / TM; gr = r0 + (idx % TM); }
             float v = 0.f;
             if (gr < rows && gk < kend) v = ldf<T>(X + (trans ? (long)gk * ld + gr : (long)gr * ld + gk));
             t.v[i] = v;
@@ -62,33 +66,35 @@ __device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, 
     }
 }
 
-template <bool VEC>
+template <bool VEC, int TM>
 __device__ __forceinline__ void store_tile(float (*S)[LDK], const TileRegs& t, int trans, int tid) {
+    constexpr int NV = TM / 32, NS = TM / 8;
     if constexpr (VEC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             if (!trans) {
                 *reinterpret_cast<float4*>(&S[idx >> 3][(idx & 7) * 4]) =
                     make_float4(t.v[4 * i], t.v[4 * i + 1], t.v[4 * i + 2], t.v[4 * i + 3]);
             } else {
-                const int kr = idx >> 4, c = (idx & 15) * 4;
+                const int kr = idx / (TM / 4), c = (idx % (TM / 4)) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) S[c + j][kr] = t.v[4 * i + j];
             }
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int idx = tid + i * 256;
             if (!trans) S[idx >> 5][idx & 31] = t.v[i];
-            else S[idx & 63][idx >> 6] = t.v[i];
+            else S[idx % TM][idx / TM] = t.v[i];
         }
     }
 }
 
-template <int PREC, typename TB, bool VECA, bool VECB>
+template <int PREC, typename TB, bool VECA, bool VECB, int TM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int BM = TM, BN = TM, WT = TM / 2, NF = TM / 32;   // wave sub-tile WT x WT = NF x NF MFMA tiles of 16 x 16
     __shared__ __attribute__((aligned(16))) float As[BM][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[BN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -104,32 +110,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int kbeg = split * per * BK;
     const int kend = min(g.K, kbeg + per * BK);
 
-    f32x4 acc[2][2];
+    f32x4 acc[NF][NF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
     TileRegs ra, rb;
     if (kbeg < kend) {
-        load_tile<float, VECA>(ra, A, g.lda, g.transA, m0, g.M, kbeg, kend, tid);
-        load_tile<TB, VECB>(rb, B, g.ldb, g.transB, n0, g.N, kbeg, kend, tid);
+        load_tile<float, VECA, TM>(ra, A, g.lda, g.transA, m0, g.M, kbeg, kend, tid);
+        load_tile<TB, VECB, TM>(rb, B, g.ldb, g.transB, n0, g.N, kbeg, kend, tid);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_tile<VECA>(As, ra, g.transA, tid);
-        store_tile<VECB>(Bs, rb, g.transB, tid);
+        store_tile<VECA, TM>(As, ra, g.transA, tid);
+        store_tile<VECB, TM>(Bs, rb, g.transB, tid);
         __syncthreads();
         if (k0 + BK < kend) {                      // next tile's loads fly while this one is multiplied
-            load_tile<float, VECA>(ra, A, g.lda, g.transA, m0, g.M, k0 + BK, kend, tid);
-            load_tile<TB, VECB>(rb, B, g.ldb, g.transB, n0, g.N, k0 + BK, kend, tid);
+            load_tile<float, VECA, TM>(ra, A, g.lda, g.transA, m0, g.M, k0 + BK, kend, tid);
+            load_tile<TB, VECB, TM>(rb, B, g.ldb, g.transB, n0, g.N, k0 + BK, kend, tid);
         }
         if constexpr (PREC == MOMA_PREC_BF16) {
-            bf16x8 af[2], bf[2];
+            bf16x8 af[NF], bf[NF];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float* pa = &As[wm * 32 + i * 16 + fr][fg * 8];
-                const float* pb = &Bs[wn * 32 + i * 16 + fr][fg * 8];
+            for (int i = 0; i < NF; ++i) {
+                const float* pa = &As[wm * WT + i * 16 + fr][fg * 8];
+                const float* pb = &Bs[wn * WT + i * 16 + fr][fg * 8];
                 const float4 a0 = *reinterpret_cast<const float4*>(pa), a1 = *reinterpret_cast<const float4*>(pa + 4);
                 const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
                 af[i] = bf16x8{(__bf16)a0.x, (__bf16)a0.y, (__bf16)a0.z, (__bf16)a0.w,
@@ -138,23 +144,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                                (__bf16)b1.x, (__bf16)b1.y, (__bf16)b1.z, (__bf16)b1.w};
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NF; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
-                float af[2], bf[2];
+                float af[NF], bf[NF];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = As[wm * 32 + i * 16 + fr][kk * 4 + fg];
-                    bf[i] = Bs[wn * 32 + i * 16 + fr][kk * 4 + fg];
+                for (int i = 0; i < NF; ++i) {
+                    af[i] = As[wm * WT + i * 16 + fr][kk * 4 + fg];
+                    bf[i] = Bs[wn * WT + i * 16 + fr][kk * 4 + fg];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NF; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NF; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -163,13 +169,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     // C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 32 + j * 16 + fr;
+        for (int j = 0; j < NF; ++j) {
+            const int col = n0 + wn * WT + j * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + fg * 4 + r;
+                const int row = m0 + wm * WT + i * 16 + fg * 4 + r;
                 if (row < g.M && col < g.N) {
                     float v = acc[i][j][r] * g.alpha;
                     if (g.bias != nullptr && split == 0) v += g.bias[col];
@@ -183,47 +189,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }  // namespace
 
 namespace {
-template <int PREC, typename TB>
+template <int PREC, typename TB, int TM>
 void launch_variant(const GemmArgs& a, dim3 grid, bool va, bool vb, hipStream_t s) {
     dim3 block(256);
-    if (va && vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, true>), grid, block, 0, s, a);
-    else if (va) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, false>), grid, block, 0, s, a);
-    else if (vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, false>), grid, block, 0, s, a);
+    if (va && vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, true, TM>), grid, block, 0, s, a);
+    else if (va) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, false, TM>), grid, block, 0, s, a);
+    else if (vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, true, TM>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, false, TM>), grid, block, 0, s, a);
 }
 inline bool vec_ok(const void* p, long ld, long stride, int batch) {
     return ((uintptr_t)p % 16) == 0 && ld % 4 == 0 && (batch == 1 || stride % 4 == 0);
 }
-}  // namespace
-
-hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
-    if (a_in.M <= 0 || a_in.N <= 0 || a_in.batch <= 0) return hipSuccess;
-    GemmArgs a = a_in;
-    const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
-    // Few output tiles (M = 256-class problems): split K over workgroups and combine with fp32 atomics into a
-    // zeroed C, so the launch covers the chip.  Only when the caller did not choose a split itself.
-    if (a.splitk == 1 && !a.atomic && tiles < 128 && a.K >= 4 * BK && a.ldc == a.N && a.batch == 1) {
-        int sk = (256 + tiles - 1) / tiles;
-        const int ktiles = (a.K + BK - 1) / BK;
-        if (sk > ktiles / 2) sk = ktiles / 2;
-        if (sk > 16) sk = 16;
-        if (sk > 1) {
-            hipError_t e = hipMemsetAsync(a.C, 0, (size_t)a.M * a.N * sizeof(float), s);
-            if (e != hipSuccess) return e;
-            a.splitk = sk;
-            a.atomic = 1;
-        }
-    }
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch * a.splitk);
+template <int TM>
+void launch_tm(const GemmArgs& a, hipStream_t s) {
+    dim3 grid((a.N + TM - 1) / TM, (a.M + TM - 1) / TM, a.batch * a.splitk);
     const bool va = vec_ok(a.A, a.lda, a.strideA, a.batch);
     const bool vb = a.b_dtype == MOMA_DT_F32 && vec_ok(a.B, a.ldb, a.strideB, a.batch);
     if (a.prec == MOMA_PREC_BF16) {
-        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_BF16, bf16_raw>(a, grid, va, false, s);
-        else launch_variant<MOMA_PREC_BF16, float>(a, grid, va, vb, s);
+        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_BF16, bf16_raw, TM>(a, grid, va, false, s);
+        else launch_variant<MOMA_PREC_BF16, float, TM>(a, grid, va, vb, s);
     } else {
-        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_F32, bf16_raw>(a, grid, va, false, s);
-        else launch_variant<MOMA_PREC_F32, float>(a, grid, va, vb, s);
+        if (a.b_dtype == MOMA_DT_BF16) launch_variant<MOMA_PREC_F32, bf16_raw, TM>(a, grid, va, false, s);
+        else launch_variant<MOMA_PREC_F32, float, TM>(a, grid, va, vb, s);
     }
+}
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
+    // Few 64 x 64 output tiles (the M = 256-class linears): 32 x 32 tiles give 4x the workgroups instead of a K split --
+    // every output element stays ONE fixed-order sum, so the results are bitwise reproducible.  (A caller that wants a K
+    // split over workgroups asks for it explicitly with splitk / atomic: only the materialised-logits gradient does.)
+    const long tiles64 = (long)((a.N + 63) / 64) * ((a.M + 63) / 64) * a.batch * a.splitk;
+    if (tiles64 < 192) launch_tm<32>(a, s);
+    else launch_tm<64>(a, s);
     return hipGetLastError();
 }
 

@@ -15,9 +15,10 @@
 //     keys in 16 registers x 2 lane halves -> row max / sum are in-register plus one cross-half wave shuffle.
 //   * each wave gets an (m, l) pair per query over its keys, merged across the waves through LDS into the row
 //     log-sum-exp; then (N <= 256: from the score registers it still holds; larger N: a second pass that
-//     recomputes the scores) it emits NORMALISED probabilities
-//     (optionally stored for the backward, transposed through LDS so the global stores are 128-B rows) and
-//     accumulates O += P . V per wave; the partial O are summed through LDS and stored as coalesced rows.
+//     recomputes the scores) it forms NORMALISED probabilities and accumulates O += P . V per wave; the partial O are
+//     summed through LDS and stored as coalesced rows.  The probabilities are never written: what the backward keeps is
+//     the row log-sum-exp lse[h][q] (log2 units, scale included) -- it recomputes P tile by tile (flash-style), so no
+//     [H, N, N] array exists at any N (attn = 'all' runs over N = 2B + K tokens).
 #include "common.hpp"
 
 namespace moma {
@@ -54,11 +55,10 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[KS], const float* __r
     }
 }
 
-template <bool STORE_P, bool ONE_TILE>
+template <bool ONE_TILE>
 __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ attn_out,
-                                                            float* __restrict__ probs, int N, int d, int H) {
-    // [NW][32][DP] fp32 partial O (128 KiB; the head of wave w's slice doubles as its 32 x 33 probability
-    // transpose stage, which the same wave is done with before it writes its O) | [NW][32][2] (m, l)
+                                                            float* __restrict__ lse_out, int N, int d, int H) {
+    // [NW][32][DP] fp32 partial O (128 KiB) | [NW][32][2] (m, l)
     __shared__ __attribute__((aligned(16))) float s_o[NW * 32 * DP];
     __shared__ float s_ml[NW * 32 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,21 +162,6 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
             }
         }
     };
-    float* pstage = s_o + wave * 32 * DP;
-    auto store_p = [&](int t, const f32x16& p) {
-        // transpose through LDS (33-float rows: conflict-free both ways) -> 128-B rows of probs[h][q][32t ..]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pstage[n * 33 + (r & 3) + 8 * (r >> 2) + 4 * h2] = p[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = 2 * i + h2, key = t * KT + n;
-            const float v = pstage[row * 33 + n];
-            if (q0 + row < N && key < N) probs[((long)head * N + q0 + row) * N + key] = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
     if constexpr (ONE_TILE) {
         // N <= 32*NW: one key tile per wave (a wave past the last tile runs fully masked).  Straight line: one round
         // of loads (Q, K, V all requested up front), scores once, two barriers, one round of stores.
@@ -191,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
         for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
         mask_v(wave);
         context(x);
-        if constexpr (STORE_P) store_p(wave, x);
+        if (lse_out != nullptr && wave == 0 && h2 == 0 && q0 + n < N) lse_out[(long)head * N + q0 + n] = lse2;
     } else {
         // pass 1: per-wave (m, l) over its key tiles; pass 2 recomputes the scores
         float m = NEG_BIG, l = 0.f;
@@ -211,8 +196,8 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
             for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
             mask_v(t);
             context(x);
-            if constexpr (STORE_P) store_p(t, x);
         }
+        if (lse_out != nullptr && wave == 0 && h2 == 0 && q0 + n < N) lse_out[(long)head * N + q0 + n] = lse2;
     }
     // ---- sum the partial O through LDS; O[c][r] is query row (r&3) + 8*(r>>2) + 4*h2, column 32c + n ----
 #pragma unroll
@@ -236,17 +221,19 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
 }
 
 // =====================================================================================================
-// Backward of the per-head core (bf16 policy), replacing four GEMM launches and the softmax-backward kernel:
+// Backward of the per-head core (bf16 policy), flash-style: P is RECOMPUTED per tile from Q, K and the forward's row
+// log-sum-exp -- nothing of size [H, N, N] is read or written.
 //   D_i  = sum_c dA[i,c] * O[i,c]                  (mha_rowdot_kernel, per head)
-//   dP   = dA_h V_h^T ;  dS = P o (dP - D) * scale
+//   S    = Q K^T * scale ;  P = 2^(S*log2e - lse2) ;  dP = dA_h V_h^T ;  dS = P o (dP - D) * scale
 //   dQ   = dS K ;  dK = dS^T Q ;  dV = P^T dA_h
 // Same shape as the forward: operands go global -> registers -> MFMA directly, a workgroup's waves split the
-// reduction tiles and their partial results are summed through LDS.  Two roles of one kernel:
-//   ROLE_Q  : workgroup = (head, 32 queries); loop over key tiles; tile X[key, q] = V_tile . dA_blk^T has the query on
-//             the lane (exactly the forward's score tile), P / dS likewise; dQ += dS . K_tile.
-//   ROLE_KV : workgroup = (head, 32 keys);    loop over query tiles; the tile is built transposed,
-//             X'[q, key] = dA_tile . V_blk^T, so that the key sits on the lane: dV += P'^T-as-A . dA_tile and
-//             dK += dS'-as-A . Q_tile use it as the MFMA A operand [key, q] without any data movement.
+// reduction tiles and their partial results are summed through LDS in a fixed order (no atomics: bitwise reproducible).
+// One launch, two roles (blockIdx.z):
+//   ROLE_Q  : workgroup = (head, 32 queries); loop over key tiles; the tiles X[key, q] = V_tile . dA_blk^T and
+//             S[key, q] = K_tile . Qs_blk^T have the query on the lane (as the forward's score tile); dQ += dS . K_tile.
+//   ROLE_KV : workgroup = (head, 32 keys);    loop over query tiles; the tiles are built transposed,
+//             X'[q, key] = dA_tile . V_blk^T and S'[q, key] = Q_tile . Ks_blk^T, so that the key sits on the lane:
+//             dV += P'-as-A . dA_tile and dK += dS'-as-A . Q_tile use them as MFMA A operands [key, q] as they stand.
 // The k index of the second product enumerates the tile's rows in the order the tile registers hold them
 // (register 8s + j <-> row 16s + 8*(j>>2) + 4*h2 + (j&3)), as in the forward.
 constexpr int BW = 4;                         // waves per workgroup in the backward (512 registers per lane each)
@@ -328,10 +315,9 @@ __device__ __forceinline__ void reduce_store(float* s_o, const f32x16 (&acc)[NCT
 }
 
 template <bool ROLE_KV>
-__global__ __launch_bounds__(BW * 64) void mha_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
-                                                             const float* __restrict__ dA, const float* __restrict__ Dv,
-                                                             float* __restrict__ dqkv, int N, int d, int H) {
-    __shared__ __attribute__((aligned(16))) float s_o[BW * 32 * DP];
+__device__ __forceinline__ void mha_core_bwd_role(float* s_o, const float* __restrict__ qkv, const float* __restrict__ lse,
+                                                  const float* __restrict__ dA, const float* __restrict__ Dv,
+                                                  float* __restrict__ dqkv, int N, int d, int H) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h2 = lane >> 5;
     const int head = blockIdx.y, hd = d / H;
@@ -341,52 +327,62 @@ __global__ __launch_bounds__(BW * 64) void mha_core_bwd_kernel(const float* __re
     const float* kb = qkv + d + head * hd;
     const float* vb = qkv + 2 * d + head * hd;
     const float* dab = dA + head * hd;
-    const float* P = probs + (long)head * N * N;
+    const float* Lh = lse + (long)head * N;
     const float* Dh = Dv + (long)head * N;
     const float scale = 1.0f / sqrtf((float)hd);
+    const float scale_log2 = scale * 1.4426950408889634f;
     const int ntiles = (N + KT - 1) / KT;
 
-    bf16x8 res[KS];                                         // resident B fragments: dA rows of the block / V rows of the block
-    if constexpr (!ROLE_KV) load_row_frags(res, dab, d, b0 + n, N, hd, h2, 1.f);
-    else load_row_frags(res, vb, ld, b0 + n, N, hd, h2, 1.f);
+    // resident B fragments of the block: ROLE_Q: dA rows and (pre-scaled) Q rows; ROLE_KV: V rows and K rows
+    bf16x8 res[KS], sres[KS];
+    if constexpr (!ROLE_KV) {
+        load_row_frags(res, dab, d, b0 + n, N, hd, h2, 1.f);
+        load_row_frags(sres, qb, ld, b0 + n, N, hd, h2, scale_log2);
+    } else {
+        load_row_frags(res, vb, ld, b0 + n, N, hd, h2, 1.f);
+        load_row_frags(sres, kb, ld, b0 + n, N, hd, h2, 1.f);          // (the scale rides on Q in both roles: same bf16 roundings
+    }                                                                   //  as the forward, so the recomputed P is the forward's P)
     f32x16 acc0[NCT], acc1[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
-    const float Dn = (!ROLE_KV && b0 + n < N) ? Dh[b0 + n] : 0.f;          // ROLE_Q: D of the lane's query
+    const bool lane_ok = b0 + n < N;                                        // the block element on this lane exists
+    const float Dn = (!ROLE_KV && lane_ok) ? Dh[b0 + n] : 0.f;              // ROLE_Q: D and lse of the lane's query
+    const float Ln = (!ROLE_KV && lane_ok) ? Lh[b0 + n] : 0.f;
 
     for (int t = wave; t < ntiles; t += BW) {
         const int t0 = t * KT;
-        // tile X = (rows of the tile as A) . (block as B): ROLE_Q: V_tile . dA_blk^T = dP[key, q];  ROLE_KV: dA_tile . V_blk^T
+        // X = (rows of the tile as A) . (block as B): ROLE_Q: V_tile . dA_blk^T = dP[key, q] ; ROLE_KV: dA_tile . V_blk^T
+        // S = likewise:                               ROLE_Q: K_tile . Qs_blk^T          ; ROLE_KV: Q_tile . Ks_blk^T
         bf16x8 af[KS];
+        f32x16 x, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x[r] = 0.f; sc[r] = 0.f; }
         if constexpr (!ROLE_KV) load_row_frags(af, vb, ld, t0 + n, N, hd, h2, 1.f);
         else load_row_frags(af, dab, d, t0 + n, N, hd, h2, 1.f);
-        f32x16 x;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], res[ks], x, 0, 0, 0);
-        // P of the tile in the same layout (tile row on the registers, block element on the lane), dS = P (dP - D) scale
+        if constexpr (!ROLE_KV) load_row_frags(af, kb, ld, t0 + n, N, hd, h2, 1.f);
+        else load_row_frags(af, qb, ld, t0 + n, N, hd, h2, scale_log2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], sres[ks], sc, 0, 0, 0);
+        // P of the tile (tile row on the registers, block element on the lane) from the row log-sum-exp; dS = P (dP - D) scale
         f32x16 p, ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tr = t0 + (r & 3) + 8 * (r >> 2) + 4 * h2;        // tile row of register r
-            const int qi = ROLE_KV ? tr : b0 + n, kj = ROLE_KV ? b0 + n : tr;
-            float pv = P[(long)min(qi, N - 1) * N + min(kj, N - 1)];
-            asm volatile("" : "+v"(pv));
-            p[r] = (qi < N && kj < N) ? pv : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float dq_;
-            if constexpr (ROLE_KV) {
-                const int qi = t0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                dq_ = Dh[min(qi, N - 1)];
+            float l_, d_;
+            if constexpr (ROLE_KV) {                                    // the query is the tile row
+                l_ = Lh[min(tr, N - 1)];
+                d_ = Dh[min(tr, N - 1)];
             } else {
-                dq_ = Dn;
+                l_ = Ln;
+                d_ = Dn;
             }
-            ds[r] = p[r] * (x[r] - dq_) * scale;
+            const float pv = __builtin_amdgcn_exp2f(sc[r] - l_);
+            p[r] = (tr < N && lane_ok) ? pv : 0.f;
+            ds[r] = p[r] * (x[r] - d_) * scale;
         }
         float vv[NCT][2][8];
         if constexpr (!ROLE_KV) {
@@ -406,6 +402,14 @@ __global__ __launch_bounds__(BW * 64) void mha_core_bwd_kernel(const float* __re
         reduce_store(s_o, acc1, dqkv + 2 * d + head * hd, ld, b0, N, hd, tid, wave, n, h2);
     }
 }
+
+__global__ __launch_bounds__(BW * 64) void mha_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ lse,
+                                                             const float* __restrict__ dA, const float* __restrict__ Dv,
+                                                             float* __restrict__ dqkv, int N, int d, int H) {
+    __shared__ __attribute__((aligned(16))) float s_o[BW * 32 * DP];
+    if (blockIdx.z == 0) mha_core_bwd_role<false>(s_o, qkv, lse, dA, Dv, dqkv, N, d, H);
+    else mha_core_bwd_role<true>(s_o, qkv, lse, dA, Dv, dqkv, N, d, H);
+}
 }  // namespace
 
 bool mha_core_fused_supported(int N, int d, int H, int prec) {
@@ -414,23 +418,19 @@ bool mha_core_fused_supported(int N, int d, int H, int prec) {
     return hd % 16 == 0 && hd <= DP && d % 4 == 0 && N >= 1;
 }
 
-// D scratch: H*N floats.  dqkv [N,3d] receives dQ | dK | dV of every head.
-hipError_t launch_mha_core_bwd(const float* qkv, const float* probs, const float* attn_out, const float* dA, float* D,
+// D scratch: H*N floats.  dqkv [N,3d] receives dQ | dK | dV of every head.  lse: the forward's [H,N] row log-sum-exp.
+hipError_t launch_mha_core_bwd(const float* qkv, const float* lse, const float* attn_out, const float* dA, float* D,
                                float* dqkv, int N, int d, int H, hipStream_t st) {
     hipLaunchKernelGGL(mha_rowdot_kernel, dim3((N * H + 3) / 4), dim3(256), 0, st, dA, attn_out, D, N, d, H);
-    const dim3 grid((N + 31) / 32, H), block(BW * 64);
-    hipLaunchKernelGGL((mha_core_bwd_kernel<false>), grid, block, 0, st, qkv, probs, dA, D, dqkv, N, d, H);
-    hipLaunchKernelGGL((mha_core_bwd_kernel<true>), grid, block, 0, st, qkv, probs, dA, D, dqkv, N, d, H);
+    const dim3 grid((N + 31) / 32, H, 2), block(BW * 64);              // z = role: 0 dQ, 1 dK | dV
+    hipLaunchKernelGGL(mha_core_bwd_kernel, grid, block, 0, st, qkv, lse, dA, D, dqkv, N, d, H);
     return hipGetLastError();
 }
 
-hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* probs, int N, int d, int H, hipStream_t st) {
+hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* lse, int N, int d, int H, hipStream_t st) {
     dim3 grid((N + 31) / 32, H), block(NW * 64);
-    const bool one = N <= KT * NW;
-    if (probs && one) hipLaunchKernelGGL((mha_core_fwd_kernel<true, true>), grid, block, 0, st, qkv, attn_out, probs, N, d, H);
-    else if (probs) hipLaunchKernelGGL((mha_core_fwd_kernel<true, false>), grid, block, 0, st, qkv, attn_out, probs, N, d, H);
-    else if (one) hipLaunchKernelGGL((mha_core_fwd_kernel<false, true>), grid, block, 0, st, qkv, attn_out, probs, N, d, H);
-    else hipLaunchKernelGGL((mha_core_fwd_kernel<false, false>), grid, block, 0, st, qkv, attn_out, probs, N, d, H);
+    if (N <= KT * NW) hipLaunchKernelGGL((mha_core_fwd_kernel<true>), grid, block, 0, st, qkv, attn_out, lse, N, d, H);
+    else hipLaunchKernelGGL((mha_core_fwd_kernel<false>), grid, block, 0, st, qkv, attn_out, lse, N, d, H);
     return hipGetLastError();
 }
 

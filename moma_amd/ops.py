@@ -270,22 +270,25 @@ class _MHA(torch.autograd.Function):
         y = torch.empty(N, d, device=dev, dtype=torch.float32)
         qkv = torch.empty(N, 3 * d, device=dev, dtype=torch.float32)
         need_bwd = grad_mode and any(ctx.needs_input_grad)      # (grad mode is always off inside forward)
-        # the fused per-head core only materialises the probabilities when a backward follows
-        probs = (None if (not need_bwd and lib.moma_mha_probs_optional(N, d, H, prec))
-                 else torch.empty(H, N, N, device=dev, dtype=torch.float32))
+        # what the backward needs besides qkv / attn_out: the fused per-head core keeps the row log-sum-exp [H,N] (it recomputes
+        # P per tile); the staged path (exact fp32, odd head dims) the probabilities [H,N,N] -- which it also computes through
+        save_lse = lib.moma_mha_saved_state(N, d, H, prec) == _lib.MHA_SAVE_LSE
+        probs = None if save_lse else torch.empty(H, N, N, device=dev, dtype=torch.float32)
+        lse = torch.empty(H, N, device=dev, dtype=torch.float32) if (save_lse and need_bwd) else None
         attn_out = torch.empty(N, d, device=dev, dtype=torch.float32)
         with _timed("moma_mha_fwd"):
             check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
-                                   _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
+                                   _ptr(probs), _ptr(lse), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
         if need_bwd:
-            ctx.save_for_backward(x, w_qkv, w_proj, qkv, probs, attn_out)
-        ctx.H, ctx.prec, ctx.has_bqkv = H, prec, b_qkv is not None
+            ctx.save_for_backward(x, w_qkv, w_proj, qkv, lse if save_lse else probs, attn_out)
+        ctx.H, ctx.prec, ctx.has_bqkv, ctx.save_lse = H, prec, b_qkv is not None, save_lse
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w_qkv, w_proj, qkv, probs, attn_out = ctx.saved_tensors
+        x, w_qkv, w_proj, qkv, state, attn_out = ctx.saved_tensors
+        probs, lse = (None, state) if ctx.save_lse else (state, None)
         dy = dy.contiguous()
         N, d = x.shape
         H = ctx.H
@@ -296,11 +299,12 @@ class _MHA(torch.autograd.Function):
         db_qkv = torch.empty(3 * d, device=dev, dtype=torch.float32) if (need[2] and ctx.has_bqkv) else None
         dw_proj = torch.empty_like(w_proj) if need[3] else None
         db_proj = torch.empty(d, device=dev, dtype=torch.float32) if need[4] else None
-        ws_bytes = lib.moma_mha_bwd_workspace_bytes(N, d, H)
+        ws_bytes = lib.moma_mha_bwd_workspace_bytes(N, d, H, ctx.prec)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(attn_out), _ptr(dy),
-                               _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
-                               ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
+        with _timed("moma_mha_bwd"):
+            check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(lse), _ptr(attn_out),
+                                   _ptr(dy), _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
+                                   ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
         return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None, None
 
 
