@@ -8,36 +8,31 @@
 //   MOMA_PREC_F32  : v_mfma_f32_16x16x4_f32  (exact fp32 fma chain = the reference's arithmetic)
 //   MOMA_PREC_BF16 : v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 at fragment load, fp32 accumulate)
 #include "common.hpp"
+#include <mutex>
 
 namespace moma {
 
 namespace {
-constexpr int BK = 32, LDK = BK + 4;  // +4 floats: 16-B aligned rows, spreads banks
-
-template <typename T> __device__ __forceinline__ float ldf(const T* p);
-template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ldf<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
-
-// One TM x BK operand tile travels global -> registers -> LDS.  The two halves are split so that the global loads
-// of tile k+1 are in flight while tile k is multiplied (the problems here are M = 256-class: latency-bound, few
-// workgroups, so nothing else hides the ~2 us of a dependent HBM/L2 round trip per k-step).
-//   X(row,k) = trans ? X[k*ld + row] : X[row*ld + k]; out-of-range elements read as zero.
-// VEC: 16-byte loads along the contiguous dimension (needs fp32 data, ld % 4 == 0, 16-B aligned base).
+// K step per LDS tile: 32 with the 64 x 64 tile, 128 with the 32 x 32 tile.  The M = 256-class linears are latency- and
+// L2-traffic-bound (a T x T tile reloads M*N*K*4*(2/T) bytes from L2: 50 MB for the qkv linear at T = 32): measured on MI355X
+// (rocprofv3, [256 x 1536 x 512]) BK = 128 -> 14.6 us average, the whole K panel at once (BK = 512) -> 18.9 us, BK = 32 -> 17.0 us.
+// Rows padded by 4 floats (16-B aligned, banks).
+template <int N>
 struct TileRegs {
-    float v[8];
+    float v[N];
 };
 
-template <typename T, bool VEC, int TM>
-__device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, long ld, int trans, int r0, int rows,
+template <typename T, bool VEC, int TM, int BK>
+__device__ __forceinline__ void load_tile(TileRegs<TM * BK / 256>& t, const T* __restrict__ X, long ld, int trans, int r0, int rows,
                                           int k0, int kend, int tid) {
-    constexpr int NV = TM / 32;                 // float4 per thread   (TM x 32 elements over 256 threads)
-    constexpr int NS = TM / 8;                  // scalars per thread
+    constexpr int NS = TM * BK / 256;           // scalars per thread   (TM x BK elements over 256 threads)
+    constexpr int NV = NS / 4;                  // float4 per thread
     if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             int gr, gk;
-            if (!trans) { gr = r0 + (idx >> 3); gk = k0 + (idx & 7) * 4; }          // 4 consecutive k of one row
+            if (!trans) { gr = r0 + idx / (BK / 4); gk = k0 + (idx % (BK / 4)) * 4; }   // 4 consecutive k of one row
             else { gk = k0 + idx / (TM / 4); gr = r0 + (idx % (TM / 4)) * 4; }      // 4 consecutive rows of one k
             const long off = trans ? (long)gk * ld + gr : (long)gr * ld + gk;
             const int lim = trans ? rows - gr : kend - gk;                          // valid elements along the vector
@@ -57,7 +52,7 @@ __device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, 
         for (int i = 0; i < NS; ++i) {
             const int idx = tid + i * 256;
             int gr, gk;
-            if (!trans) { gr = r0 + (idx >> 5); gk = k0 + (idx & 31); }
+            if (!trans) { gr = r0 + idx / BK; gk = k0 + (idx % BK); }
             else { gk = k0 + idx / TM; gr = r0 + (idx % TM); }
             float v = 0.f;
             if (gr < rows && gk < kend) v = ldf<T>(X + (trans ? (long)gk * ld + gr : (long)gr * ld + gk));
@@ -66,15 +61,15 @@ __device__ __forceinline__ void load_tile(TileRegs& t, const T* __restrict__ X, 
     }
 }
 
-template <bool VEC, int TM>
-__device__ __forceinline__ void store_tile(float (*S)[LDK], const TileRegs& t, int trans, int tid) {
-    constexpr int NV = TM / 32, NS = TM / 8;
+template <bool VEC, int TM, int BK>
+__device__ __forceinline__ void store_tile(float (*S)[BK + 4], const TileRegs<TM * BK / 256>& t, int trans, int tid) {
+    constexpr int NS = TM * BK / 256, NV = NS / 4;
     if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             if (!trans) {
-                *reinterpret_cast<float4*>(&S[idx >> 3][(idx & 7) * 4]) =
+                *reinterpret_cast<float4*>(&S[idx / (BK / 4)][(idx % (BK / 4)) * 4]) =
                     make_float4(t.v[4 * i], t.v[4 * i + 1], t.v[4 * i + 2], t.v[4 * i + 3]);
             } else {
                 const int kr = idx / (TM / 4), c = (idx % (TM / 4)) * 4;
@@ -86,7 +81,7 @@ __device__ __forceinline__ void store_tile(float (*S)[LDK], const TileRegs& t, i
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int idx = tid + i * 256;
-            if (!trans) S[idx >> 5][idx & 31] = t.v[i];
+            if (!trans) S[idx / BK][idx % BK] = t.v[i];
             else S[idx % TM][idx / TM] = t.v[i];
         }
     }
@@ -94,9 +89,11 @@ __device__ __forceinline__ void store_tile(float (*S)[LDK], const TileRegs& t, i
 
 template <int PREC, typename TB, bool VECA, bool VECB, int TM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int BK = TM == 32 ? 128 : 32, LDK = BK + 4;
     constexpr int BM = TM, BN = TM, WT = TM / 2, NF = TM / 32;   // wave sub-tile WT x WT = NF x NF MFMA tiles of 16 x 16
-    __shared__ __attribute__((aligned(16))) float As[BM][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[BN][LDK];
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    float (*As)[LDK] = reinterpret_cast<float (*)[LDK]>(gemm_smem);
+    float (*Bs)[LDK] = reinterpret_cast<float (*)[LDK]>(gemm_smem + BM * LDK);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
@@ -117,37 +114,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    TileRegs ra, rb;
+    TileRegs<TM * BK / 256> ra, rb;
     if (kbeg < kend) {
-        load_tile<float, VECA, TM>(ra, A, g.lda, g.transA, m0, g.M, kbeg, kend, tid);
-        load_tile<TB, VECB, TM>(rb, B, g.ldb, g.transB, n0, g.N, kbeg, kend, tid);
+        load_tile<float, VECA, TM, BK>(ra, A, g.lda, g.transA, m0, g.M, kbeg, kend, tid);
+        load_tile<TB, VECB, TM, BK>(rb, B, g.ldb, g.transB, n0, g.N, kbeg, kend, tid);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_tile<VECA, TM>(As, ra, g.transA, tid);
-        store_tile<VECB, TM>(Bs, rb, g.transB, tid);
+        store_tile<VECA, TM, BK>(As, ra, g.transA, tid);
+        store_tile<VECB, TM, BK>(Bs, rb, g.transB, tid);
         __syncthreads();
         if (k0 + BK < kend) {                      // next tile's loads fly while this one is multiplied
-            load_tile<float, VECA, TM>(ra, A, g.lda, g.transA, m0, g.M, k0 + BK, kend, tid);
-            load_tile<TB, VECB, TM>(rb, B, g.ldb, g.transB, n0, g.N, k0 + BK, kend, tid);
+            load_tile<float, VECA, TM, BK>(ra, A, g.lda, g.transA, m0, g.M, k0 + BK, kend, tid);
+            load_tile<TB, VECB, TM, BK>(rb, B, g.ldb, g.transB, n0, g.N, k0 + BK, kend, tid);
         }
         if constexpr (PREC == MOMA_PREC_BF16) {
-            bf16x8 af[NF], bf[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const float* pa = &As[wm * WT + i * 16 + fr][fg * 8];
-                const float* pb = &Bs[wn * WT + i * 16 + fr][fg * 8];
-                const float4 a0 = *reinterpret_cast<const float4*>(pa), a1 = *reinterpret_cast<const float4*>(pa + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
-                af[i] = bf16x8{(__bf16)a0.x, (__bf16)a0.y, (__bf16)a0.z, (__bf16)a0.w,
-                               (__bf16)a1.x, (__bf16)a1.y, (__bf16)a1.z, (__bf16)a1.w};
-                bf[i] = bf16x8{(__bf16)b0.x, (__bf16)b0.y, (__bf16)b0.z, (__bf16)b0.w,
-                               (__bf16)b1.x, (__bf16)b1.y, (__bf16)b1.z, (__bf16)b1.w};
+            for (int k32 = 0; k32 < BK / 32; ++k32) {
+                bf16x8 af[NF], bf[NF];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const float* pa = &As[wm * WT + i * 16 + fr][k32 * 32 + fg * 8];
+                    const float* pb = &Bs[wn * WT + i * 16 + fr][k32 * 32 + fg * 8];
+                    const float4 a0 = *reinterpret_cast<const float4*>(pa), a1 = *reinterpret_cast<const float4*>(pa + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 4);
+                    af[i] = bf16x8{(__bf16)a0.x, (__bf16)a0.y, (__bf16)a0.z, (__bf16)a0.w,
+                                   (__bf16)a1.x, (__bf16)a1.y, (__bf16)a1.z, (__bf16)a1.w};
+                    bf[i] = bf16x8{(__bf16)b0.x, (__bf16)b0.y, (__bf16)b0.z, (__bf16)b0.w,
+                                   (__bf16)b1.x, (__bf16)b1.y, (__bf16)b1.z, (__bf16)b1.w};
+                }
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < NF; ++i)
-#pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -189,13 +189,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }  // namespace
 
 namespace {
+template <int PREC, typename TB, bool VA, bool VB, int TM>
+void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int BK = TM == 32 ? 128 : 32;
+    constexpr size_t lds = (size_t)2 * TM * (BK + 4) * sizeof(float);
+    if constexpr (lds > 64 * 1024) {                       // dynamic-LDS opt-in, once per process and instantiation
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel<PREC, TB, VA, VB, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+    }
+    hipLaunchKernelGGL((gemm_kernel<PREC, TB, VA, VB, TM>), grid, dim3(256), lds, s, a);
+}
 template <int PREC, typename TB, int TM>
 void launch_variant(const GemmArgs& a, dim3 grid, bool va, bool vb, hipStream_t s) {
-    dim3 block(256);
-    if (va && vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, true, TM>), grid, block, 0, s, a);
-    else if (va) hipLaunchKernelGGL((gemm_kernel<PREC, TB, true, false, TM>), grid, block, 0, s, a);
-    else if (vb) hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, true, TM>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<PREC, TB, false, false, TM>), grid, block, 0, s, a);
+    if (va && vb) launch_one<PREC, TB, true, true, TM>(a, grid, s);
+    else if (va) launch_one<PREC, TB, true, false, TM>(a, grid, s);
+    else if (vb) launch_one<PREC, TB, false, true, TM>(a, grid, s);
+    else launch_one<PREC, TB, false, false, TM>(a, grid, s);
 }
 inline bool vec_ok(const void* p, long ld, long stride, int batch) {
     return ((uintptr_t)p % 16) == 0 && ld % 4 == 0 && (batch == 1 || stride % 4 == 0);

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void infonce_slab_dq_kernel(const unsigned* __
 
 // merge the key chunks of the 8 query rows of one (wave block, g, h) group -- they share the packed 16-B O words -- for one
 // group of 64 columns: add the positive logit (exact fp32), emit loss / lse / top-1 (column group 0 only) and dq.
-// Scalars: 32 threads per row.  dq: the 256 threads are 4 chunk-groups x 64 columns, one 16-B load (8 rows of a column) per
+// Scalars: 32 threads per row.  dq: the 256 threads are 8 chunk-groups x 32 columns, one 16-B load (8 rows of a column) per
 // thread and chunk; the chunk-groups are summed through LDS in a fixed order (bitwise reproducible).
 constexpr int COMBINE_MAX_CHUNKS = 1024;
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq) {
     __shared__ __attribute__((aligned(16))) float wts[COMBINE_MAX_CHUNKS][8];
-    __shared__ float accs[4][8][64];
+    __shared__ float accs[8][8][32];
     __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
     const int tid = threadIdx.x;
     const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;
@@ -902,8 +902,10 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
     }
     if (dq == nullptr) return;
     __syncthreads();                                                     // wts[][], rowc[][] complete
-    const int col = tid & 63, cg = tid >> 6;
-    const int column = blockIdx.y * 64 + col, c = column >> 5, n = column & 31;
+    // dq: one 32-column tile of O per block; the 256 threads are 8 chunk-groups x 32 columns, every thread keeps up to 16 loads
+    // of 16 B in flight (the kernel is one dependent sweep over 32 MB of partials: what matters is bytes in flight per CU)
+    const int col = tid & 31, cg = tid >> 5;
+    const int c = blockIdx.y, n = col;
     const int nct = D / 32;
     const long wb_stride = (long)nct * 2 * 64;                           // uint4 per wave block
     const long chunk_stride = (long)(Bpad / 32) * wb_stride;
@@ -922,24 +924,25 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         acc[7] = fmaf(w1.w, __uint_as_float(v.w & 0xffff0000u), acc[7]);
     };
     int ck = cg;
-    for (; ck + 28 < nchunk; ck += 32) {                                 // 8 loads in flight per lane
-        uint4 v[8];
+    for (; ck + 120 < nchunk; ck += 128) {                               // 16 loads in flight per lane
+        uint4 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(long)(ck + 4 * u) * chunk_stride];
+        for (int u = 0; u < 16; ++u) v[u] = src[(long)(ck + 8 * u) * chunk_stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) fma8(v[u], ck + 4 * u);
+        for (int u = 0; u < 16; ++u) fma8(v[u], ck + 8 * u);
     }
-    for (; ck < nchunk; ck += 4) fma8(src[(long)ck * chunk_stride], ck);
+    for (; ck < nchunk; ck += 8) fma8(src[(long)ck * chunk_stride], ck);
 #pragma unroll
     for (int i = 0; i < 8; ++i) accs[cg][i][col] = acc[i];
     __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int i = cg + 4 * half;
+    {
+        const int i = cg;                                                // 8 rows x 32 columns of output, one per thread
         const int b = row_of(i);
         if (b < B) {
-            const float a = ((accs[0][i][col] + accs[1][i][col]) + accs[2][i][col]) + accs[3][i][col];
-            const long o = (long)b * D + column;
+            float a = accs[0][i][col];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) a += accs[u][i][col];           // fixed order: bitwise reproducible
+            const long o = (long)b * D + c * 32 + col;
             dq[o] = (rowc[i][1] * k[o] + a * rowc[i][0]) * inv_T;
         }
     }
@@ -1072,7 +1075,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 64 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
+    hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
                        p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq);
     return hipGetLastError();
 }

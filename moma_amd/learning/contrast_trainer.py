@@ -39,8 +39,8 @@ class ContrastTrainer(BaseTrainer):
 
         Like the reference's zip over parameters() this requires identical architectures; a shape mismatch
         raises RuntimeError -- before touching the teacher, unlike the reference which fails half-way (Q4)."""
-        ps = [p.detach() for p in model.parameters()]
-        es = [p.detach() for p in model_ema.parameters()]
+        ps = list(model.parameters())          # (data_ptr / numel are read straight off the parameters: a detach() per tensor
+        es = list(model_ema.parameters())      #  and call doubles the host time of this call -- ~0.5 ms for EfficientNet-B0)
         key = (id(model), id(model_ema))
         tabs = ContrastTrainer._ema_tables
         tab = tabs.get(key)

@@ -56,8 +56,9 @@ def _install_cpu_standins():
             return True
 
     def ema_update_(table, m):
-        for p, e in zip(table.ps, table.es):
-            e.mul_(m).add_(p, alpha=1 - m)
+        with torch.no_grad():
+            for p, e in zip(table.ps, table.es):
+                e.mul_(m).add_(p, alpha=1 - m)
 
     ops.mha, ops.infonce_fused, ops.enqueue_, ops.EmaTable, ops.ema_update_ = mha, infonce_fused, enqueue_, EmaTable, ema_update_
 
