@@ -128,24 +128,56 @@ class KernelEvents:
         return tot / len(self.pairs)
 
 
-def k2_pmc_traffic():
-    """HBM bytes per launch of the one-pass kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of scripts/bench_k2.py on the bench shape, summarised in profiles/): FETCH_SIZE is doubled per
-    the guide's gfx950 correction.  None when no summary is present."""
-    import csv
+def _latest_profile(pattern):
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k2_hbm_traffic.csv"))):
-        fetch = write = None
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return fs[-1] if fs else None
+
+
+def k2_pmc_traffic():
+    """HBM bytes per launch of the one-pass kernel from the newest committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of scripts/bench_k2.py on the bench shape, summarised in profiles/rNN_k2_pmc.csv): FETCH_SIZE is
+    doubled per the guide's gfx950 correction.  None when no summary is present."""
+    import csv
+    f = _latest_profile("r*_k2_pmc.csv")
+    if f is None:
+        return None
+    fetch = write = None
+    for r in csv.DictReader(open(f)):
+        if r["kernel"].startswith("moma::infonce_flash_kernel<512, true>"):
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["mean_per_launch"])
+            if r["counter"] == "WRITE_SIZE":
+                write = float(r["mean_per_launch"])
+    if fetch is None or write is None:
+        return None
+    return int((2 * fetch + write) * 1024)
+
+
+def pmc_fracs():
+    """In-kernel utilisation figures from the newest committed SQ-counter summaries (profiles/rNN_k2_pmc.csv, rNN_k1_pmc.csv;
+    rocprofv3 --pmc on scripts/bench_k2.py / bench_k1.py): matrix-pipe busy share of the busy cycles, stall shares."""
+    import csv
+    out = {}
+    for tag, pat, kernels in (("k2", "r*_k2_pmc.csv", ("moma::infonce_flash_kernel<512, true>",)),
+                              ("k1", "r*_k1_pmc.csv", ("moma::mha_core_fwd_kernel<true>", "moma::mha_core_bwd_kernel"))):
+        f = _latest_profile(pat)
+        if f is None:
+            continue
+        vals = {}
         for r in csv.DictReader(open(f)):
-            if "infonce_flash_kernel<512, true, false>" in r["kernel"]:
-                if r["counter"] == "FETCH_SIZE":
-                    fetch = float(r["mean_per_launch"])
-                if r["counter"] == "WRITE_SIZE":
-                    write = float(r["mean_per_launch"])
-        if fetch is not None and write is not None:
-            best = int((2 * fetch + write) * 1024)
-    return best
+            for kn in kernels:
+                if r["kernel"].startswith(kn):
+                    vals.setdefault(kn, {})[r["counter"]] = float(r["mean_per_launch"])
+        for kn, c in vals.items():
+            # SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_WAIT_* quad-cycles (guide, cycle table)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0:
+                key = kn.split("::")[-1]
+                out[key] = {"mfma_busy_frac_of_wave_cycles": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"]), 4),
+                            "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                            "wait_inst_any_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                            "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "source": os.path.basename(f)}
+    return out
 
 
 def k2_algorithmic(B, d, K, qbytes):
@@ -312,7 +344,7 @@ def main():
         d = contrast.memory.shape[1]
         qbytes = contrast.memory.element_size()
         k2_ms = kev.mean_ms()                         # the one-pass kernel alone (events recorded by the library)
-        k2_call_ms = rec.mean_ms("moma_infonce_fused")  # whole C-ABI call: q pre-pack + pass + repair check + combine
+        k2_call_ms = rec.mean_ms("moma_infonce_fused")  # whole C-ABI call: q pre-pack + one pass + combine
         bytes_, flops = k2_algorithmic(a.batch_size, d, a.nce_k, qbytes)
         # governing bound = the larger ideal time: HBM for a 4-byte queue, MFMA for bf16 at B=256
         t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
@@ -326,6 +358,22 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         if (a.batch_size, d, a.nce_k, a.queue_dtype) == (256, 512, 65536, "bf16"):
             roof["traffic"] = k2_pmc_traffic()          # bytes per launch (PMC, committed summary)
+        k1f, k1b, k4 = rec.mean_ms("moma_mha_fwd"), rec.mean_ms("moma_mha_bwd"), rec.mean_ms("moma_ema_multi")
+        n_par = sum(p.numel() for p in model_s.parameters())
+        d_att = d
+        other = {"pmc": pmc_fracs()}
+        if k4:
+            # (two K4 calls per step: backbone pair and mlp head pair; the mean is dominated by the 48 MB backbone call)
+            other["k4_ema"] = {"ms_per_call_in_step": round(k4, 4), "algorithmic_bytes_backbone": 12 * n_par,
+                               "note": "HIP events around the C-ABI call on the side stream, concurrent with the student forward; "
+                                       "alone (scripts/bench_k4.py, profiles/) the 48.2 MB call runs in ~10 us"}
+        if k1f:
+            fl = 8.0 * a.batch_size * d_att * d_att + 4.0 * a.batch_size * a.batch_size * d_att
+            other["k1_attention"] = {"fwd_ms_per_module_call": round(k1f, 4), "bwd_ms_per_call": round(k1b, 4) if k1b else None,
+                                     "fwd_flops": fl, "fwd_mfma_frac_wallclock": round(fl / (k1f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5),
+                                     "note": "launch / latency bound at N = batch (0.67 GFLOP per module call): the in-kernel "
+                                             "matrix-pipe share is in pmc.mha_core_*"}
+        roof["other"] = other
         roof.update({"kernel": "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)",
                      "ms_per_launch": round(k2_ms, 4), "whole_call_ms": round(k2_call_ms, 4),
                      "algorithmic_bytes": bytes_, "algorithmic_flops": flops,

@@ -75,6 +75,10 @@ int moma_ema_multi(const int64_t* table, int n_tensors, int64_t total_blocks,
  * ------------------------------------------------------------------------------------------- */
 int moma_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d,
                  int qdtype, moma_stream_t stream);
+/* The same enqueue into an fp32 queue (the reference's storage) AND its bf16 mirror (what the bf16-policy one-pass K2 streams:
+ * half the HBM bytes per step, no conversion pass over the K x d queue) in ONE launch from one read of the rows. */
+int moma_enqueue_mirror(float* queue, void* mirror_bf16, const float* rows, int n, int64_t index, int K, int d,
+                        moma_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  InfoNCE over the queue.

@@ -103,9 +103,13 @@ class MoCo(BaseMoCo):
             shadow = self._bf16_shadow()
         loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision)
         all_k = all_k if all_k is not None else k
-        self._update_memory(all_k, self.memory)
         if shadow is not None:
-            self._update_memory(all_k, shadow)            # same rows, rounded to bf16 (keeps the mirror exact)
+            # fp32 `memory` and its bf16 mirror in ONE launch (same rows, rounded to bf16: the mirror stays exact)
+            with torch.no_grad():
+                ops.enqueue_mirror_(self.memory, shadow, all_k.detach().contiguous().float(), self.index)
+            self._shadow_key = (self.memory.data_ptr(), self.memory._version, tuple(self.memory.shape))
+        else:
+            self._update_memory(all_k, self.memory)
         self._update_pointer(all_k.size(0))
         return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
 

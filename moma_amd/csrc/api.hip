@@ -63,6 +63,15 @@ int moma_enqueue(void* queue, const float* rows, int n, int64_t index, int K, in
     return hip_rc(launch_enqueue(queue, rows, n, index, K, d, qdtype, (hipStream_t)stream));
 }
 
+int moma_enqueue_mirror(float* queue, void* mirror_bf16, const float* rows, int n, int64_t index, int K, int d,
+                        moma_stream_t stream) {
+    if (n == 0) return MOMA_OK;
+    if (!queue || !mirror_bf16 || !rows) return MOMA_E_NULL;
+    if (n < 0 || K <= 0 || d <= 0 || index < 0 || index >= K) return MOMA_E_SHAPE;
+    if (misaligned(rows, 4) || misaligned(queue, 4) || misaligned(mirror_bf16, 2)) return MOMA_E_ALIGN;
+    return hip_rc(launch_enqueue_mirror(queue, mirror_bf16, rows, n, index, K, d, (hipStream_t)stream));
+}
+
 int moma_infonce_logits(const float* q, const float* k, const void* queue, float* out, int B, int d, int K,
                         float inv_T, int qdtype, int prec, moma_stream_t stream) {
     if (!q || !k || !queue || !out) return MOMA_E_NULL;

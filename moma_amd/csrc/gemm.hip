@@ -17,6 +17,14 @@ namespace {
 // L2-traffic-bound (a T x T tile reloads M*N*K*4*(2/T) bytes from L2: 50 MB for the qkv linear at T = 32): measured on MI355X
 // (rocprofv3, [256 x 1536 x 512]) BK = 128 -> 14.6 us average, the whole K panel at once (BK = 512) -> 18.9 us, BK = 32 -> 17.0 us.
 // Rows padded by 4 floats (16-B aligned, banks).
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
+
+// One TM x BK operand tile travels global -> registers -> LDS.  The two halves are split so that the global loads
+// of tile k+1 are in flight while tile k is multiplied.
+//   X(row,k) = trans ? X[k*ld + row] : X[row*ld + k]; out-of-range elements read as zero.
+// VEC: 16-byte loads along the contiguous dimension (needs fp32 data, ld % 4 == 0, 16-B aligned base).
 template <int N>
 struct TileRegs {
     float v[N];

@@ -35,6 +35,32 @@ __global__ __launch_bounds__(256) void enqueue_kernel(TQ* __restrict__ queue, co
     }
 }
 
+// the same for an fp32 queue AND its bf16 mirror in one launch: both rows come from one read of the source row
+__global__ __launch_bounds__(256) void enqueue_mirror_kernel(float* __restrict__ queue, bf16_raw* __restrict__ mirror,
+                                                             const float* __restrict__ rows, int n, int64_t index, int K, int d) {
+    const int i = blockIdx.x;
+    if ((int64_t)i + K < n) return;
+    const int64_t slot = (index + i) % K;
+    const float* src = rows + (int64_t)i * d;
+    float* dst = queue + slot * d;
+    bf16_raw* dm = mirror + slot * d;
+    const bool vec = ((((uintptr_t)queue | (uintptr_t)rows) & 15) == 0) && (((uintptr_t)mirror & 7) == 0) && d % 4 == 0;
+    if (vec) {
+        for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(dst + c) = v;
+            ushort4 o;
+            o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+            *reinterpret_cast<ushort4*>(dm + c) = o;
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) {
+            dst[c] = src[c];
+            dm[c] = f32_to_bf16(src[c]);
+        }
+    }
+}
+
 // ema = fma(1-m, p, ema*m) over a table of tensors   (learning/contrast_trainer.py:207-211)
 __global__ __launch_bounds__(256) void ema_kernel(const int64_t* __restrict__ table, int n_tensors, float m, float om) {
     const int64_t blk = blockIdx.x;
@@ -81,6 +107,12 @@ hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, 
         if (a16 && d % 4 == 0) hipLaunchKernelGGL((enqueue_kernel<float, true>), grid, block, 0, st, (float*)queue, rows, n, index, K, d);
         else hipLaunchKernelGGL((enqueue_kernel<float, false>), grid, block, 0, st, (float*)queue, rows, n, index, K, d);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_enqueue_mirror(float* queue, void* mirror, const float* rows, int n, int64_t index, int K, int d, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(enqueue_mirror_kernel, dim3(n), dim3(256), 0, st, queue, (bf16_raw*)mirror, rows, n, index, K, d);
     return hipGetLastError();
 }
 

@@ -154,6 +154,17 @@ def enqueue_(queue: torch.Tensor, rows: torch.Tensor, index: int) -> None:
           "moma_enqueue")
 
 
+def enqueue_mirror_(queue: torch.Tensor, mirror: torch.Tensor, rows: torch.Tensor, index: int) -> None:
+    """fp32 queue + its bf16 mirror, one launch (moma_enqueue_mirror)."""
+    lib = _lib.load()
+    _dev(queue, "queue"); _dev(mirror, "mirror", torch.bfloat16); _dev(rows, "rows")
+    K, d = queue.shape
+    if mirror.shape != queue.shape or rows.dim() != 2 or rows.shape[1] != d:
+        raise ValueError(f"rows must be [n,{d}] and mirror {tuple(queue.shape)}, got {tuple(rows.shape)} / {tuple(mirror.shape)}")
+    check(lib.moma_enqueue_mirror(_ptr(queue), _ptr(mirror), _ptr(rows), rows.shape[0], int(index), K, d, _stream()),
+          "moma_enqueue_mirror")
+
+
 # ------------------------------------------------------------------------------------------------
 # K2 InfoNCE
 # ------------------------------------------------------------------------------------------------
