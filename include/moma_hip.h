@@ -80,6 +80,12 @@ int moma_enqueue(void* queue, const float* rows, int n, int64_t index, int K, in
 int moma_enqueue_mirror(float* queue, void* mirror_bf16, const float* rows, int n, int64_t index, int K, int d,
                         moma_stream_t stream);
 
+/* Cache hint for K2: streams `bytes` of the queue once (16-B loads, data dropped) so that it sits in the 256 MiB memory-side
+ * Infinity Cache when moma_infonce_fused reads it next.  In the training step the K x d queue was last touched a whole step
+ * (gigabytes of activations) ago; issued on a second stream under the latency-bound attention launches that precede K2, the
+ * sweep costs no step time and K2 then runs at its cache-resident rate.  Purely a performance hint: no result depends on it. */
+int moma_queue_prefetch(const void* queue, size_t bytes, moma_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2  InfoNCE over the queue.
  *

@@ -92,6 +92,15 @@ class MoCo(BaseMoCo):
             self._shadow_key = key
         return self._shadow
 
+    def prefetch(self, stream=None):
+        """Cache hint before forward_fused: sweep the queue the one-pass kernel will stream (the bf16 mirror under fp32 storage)
+        into the Infinity Cache, on a side stream while latency-bound work runs on the main one.  No effect on results."""
+        mem = self.memory
+        if mem.is_cuda and mem.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16:
+            mem = self._bf16_shadow()
+        if mem.is_cuda:
+            ops.queue_prefetch(mem, stream)
+
     def forward_fused(self, q, k, all_k=None):
         """One pass over the queue -> (loss_kd, top-1 accuracy in percent [1]); then enqueue.
 

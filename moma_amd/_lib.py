@@ -30,6 +30,7 @@ SIGNATURES = {
     "moma_ema_multi": (_i, [_p, _i, _l, _f, _f, _p]),
     "moma_enqueue": (_i, [_p, _p, _i, _l, _i, _i, _i, _p]),
     "moma_enqueue_mirror": (_i, [_p, _p, _p, _i, _l, _i, _i, _p]),
+    "moma_queue_prefetch": (_i, [_p, _z, _p]),
     "moma_infonce_logits": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "moma_infonce_logits_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "moma_infonce_logits_bwd_kq": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),

@@ -72,6 +72,13 @@ int moma_enqueue_mirror(float* queue, void* mirror_bf16, const float* rows, int 
     return hip_rc(launch_enqueue_mirror(queue, mirror_bf16, rows, n, index, K, d, (hipStream_t)stream));
 }
 
+int moma_queue_prefetch(const void* queue, size_t bytes, moma_stream_t stream) {
+    if (bytes == 0) return MOMA_OK;
+    if (!queue) return MOMA_E_NULL;
+    if (misaligned(queue, 16)) return MOMA_E_ALIGN;
+    return hip_rc(launch_prefetch(queue, bytes, (hipStream_t)stream));
+}
+
 int moma_infonce_logits(const float* q, const float* k, const void* queue, float* out, int B, int d, int K,
                         float inv_T, int qdtype, int prec, moma_stream_t stream) {
     if (!q || !k || !queue || !out) return MOMA_E_NULL;

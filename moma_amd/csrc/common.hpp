@@ -70,6 +70,7 @@ hipError_t launch_pos_grad_init(const float* dlogits, long ld, const float* k, f
 // ---- queue.hip -----------------------------------------------------------------------------------
 hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d, int qdtype, hipStream_t st);
 hipError_t launch_enqueue_mirror(float* queue, void* mirror, const float* rows, int n, int64_t index, int K, int d, hipStream_t st);
+hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t st);
 hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks, float m, float om, hipStream_t st);
 
 // ---- infonce_fused.hip (one-pass flash-style kernel) ----------------------------------------------

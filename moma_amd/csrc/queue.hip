@@ -61,6 +61,17 @@ __global__ __launch_bounds__(256) void enqueue_mirror_kernel(float* __restrict__
     }
 }
 
+// Touch `bytes` of memory with streaming 16-B loads and drop the data: pulls the lines into the memory-side Infinity Cache
+// (256 MiB) so that the kernel that streams them next reads them at cache latency instead of HBM latency.  A hint only.
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16) {
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];                 // (default cache policy: the point is that the lines STAY in the caches)
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+    }
+    asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));          // keep the loads
+}
+
 // ema = fma(1-m, p, ema*m) over a table of tensors   (learning/contrast_trainer.py:207-211)
 __global__ __launch_bounds__(256) void ema_kernel(const int64_t* __restrict__ table, int n_tensors, float m, float om) {
     const int64_t blk = blockIdx.x;
@@ -113,6 +124,15 @@ hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, 
 hipError_t launch_enqueue_mirror(float* queue, void* mirror, const float* rows, int n, int64_t index, int K, int d, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(enqueue_mirror_kernel, dim3(n), dim3(256), 0, st, queue, (bf16_raw*)mirror, rows, n, index, K, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t st) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)p, n16);
     return hipGetLastError();
 }
 

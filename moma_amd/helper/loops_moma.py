@@ -158,6 +158,10 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                     f_s, k, all_k = trainer._shuffle_bn_attn(images, teacher, criterion_kd.embed_t, criterion_kd, f_s)
                 f_s, k, all_k = f_s.float(), k.float(), all_k.float()
             elif opt.attn == "self" and not mocoatt:                                      # K1, query side (:326)
+                if overlap and fused and getattr(opt, "prefetch_queue", True) and hasattr(contrast, "prefetch"):
+                    # the queue was last read a whole step ago: sweep it into the Infinity Cache on the side stream while the
+                    # (launch-latency-bound) attention module runs here; K2 then streams it at cache latency
+                    contrast.prefetch(stream=side)
                 f_s = criterion_kd.atts_q(f_s)
 
             if mocoatt:

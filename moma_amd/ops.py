@@ -154,6 +154,14 @@ def enqueue_(queue: torch.Tensor, rows: torch.Tensor, index: int) -> None:
           "moma_enqueue")
 
 
+def queue_prefetch(queue: torch.Tensor, stream=None) -> None:
+    """Cache hint (moma_queue_prefetch): sweep the queue into the Infinity Cache on `stream` (default: current)."""
+    lib = _lib.load()
+    _dev(queue, "queue", None)
+    st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(lib.moma_queue_prefetch(_ptr(queue), queue.numel() * queue.element_size(), st), "moma_queue_prefetch")
+
+
 def enqueue_mirror_(queue: torch.Tensor, mirror: torch.Tensor, rows: torch.Tensor, index: int) -> None:
     """fp32 queue + its bf16 mirror, one launch (moma_enqueue_mirror)."""
     lib = _lib.load()
