@@ -38,11 +38,11 @@
 // from a word of LDS behind the tile ring, copied out to this buffer at the end of the kernel.
 //   word 0..2: per-tile phase sums (scores, P.K || softmax, wait + barrier); 3: entry -> first barrier; 4: first tile;
 //   5: tile loop; 6: epilogue issue.
-__device__ unsigned moma_k2_stamps[1024 * 8];
+__device__ unsigned moma_k2_stamps[1024 * 16];
 extern "C" int moma_debug_read_stamps(unsigned* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned) * 1024 * 8);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned) * 1024 * 16);
 }
-#define K2_STAMP_BYTES 256
+#define K2_STAMP_BYTES 512
 // stamp now: word `neg` -= t, word `pos` += t  (either may be -1)
 #define K2_STAMP(neg, pos)                                                                                   \
     do {                                                                                                     \
@@ -50,7 +50,7 @@ extern "C" int moma_debug_read_stamps(unsigned* host) {
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t64)::"memory");                         \
         const unsigned _t = (unsigned)_t64;                                                                  \
-        const unsigned _a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem) + (unsigned)(NBUF * TILE_BYTES + 16 + wave * 32); \
+        const unsigned _a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem) + (unsigned)(NBUF * TILE_BYTES + 16 + wave * 64); \
         if ((neg) >= 0) asm volatile("ds_sub_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((neg) < 0 ? 0 : (neg) * 4) : "memory"); \
         if ((pos) >= 0) asm volatile("ds_add_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((pos) < 0 ? 0 : (pos) * 4) : "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -191,8 +191,9 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
 #ifdef MOMA_K2_STAMPS
-    if (lane < 8) reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 8 + lane] = 0u;
+    if (lane < 16) reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 16 + lane] = 0u;
     K2_STAMP(3, -1);
+    K2_STAMP(7, -1);
 #endif
 
     // block -> (query tile, key chunk): the nbt tiles of one chunk are 8 block ids apart (same XCD)
@@ -240,6 +241,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #ifndef MOMA_K2_T0_FIRST
     load_q();
 #endif
+    K2_STAMP(8, 7);
 
     // LDS-DMA ring.  Every wave issues PPW pieces per tile, in tile order, so "all but the newest j tiles of
     // this wave have landed" is s_waitcnt vmcnt(j*PPW); the workgroup barrier then makes the other waves'
@@ -259,7 +261,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #ifndef MOMA_K2_PRO
 #define MOMA_K2_PRO 4
 #endif
-    constexpr int PRO = MOMA_K2_PRO;                   // tiles requested BEFORE the first wait; the rest of the ring right after it
+    // Tiles requested BEFORE the first wait.  An LDS-DMA piece costs ~150 cycles of issue when nothing else runs (the CU's
+    // address path moves 64 B/clk: the 4 x 32 KiB ring alone is 2 k cycles of it, measured 4.7 k) and ~nothing in the shadow of
+    // MFMAs, so the pipelined kernel requests only two tiles up front and fills the rest of the ring from the first tile's
+    // scores (tile t0+2) and the first loop iteration (tile t0+3), exactly like the steady-state refills.
+    constexpr int PRO = (WITH_DQ && MODE == 0) ? 2 : MOMA_K2_PRO;
     auto issue_ring = [&](auto first_pass, int jb, int je) __attribute__((always_inline)) {
         int tb = t0;
         asm volatile("" : "+s"(tb));                   // (opaque: the two passes do not share hoisted source addresses)
@@ -272,6 +278,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         }
     };
     issue_ring(std::true_type{}, 0, PRO);
+    K2_STAMP(9, 8);
 
     f32x16 O[WITH_DQ ? NCT : 1];
     float l_run = 0.f, mx = NEG_BIG;
@@ -301,8 +308,75 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // of the MFMAs that consume them; the sched_barriers pin "issue reads, then MFMAs" (left alone, hipcc sinks the
     // reads behind the MFMAs and exposes the LDS latency once per group).  One LDS-DMA piece of the refill tile is
     // issued after every 4th MFMA, so its issue cost hides behind the matrix pipe.
-    auto score = [&](auto refill_tag, const char* buf, f32x16& x, float init, long rkey0, char* rbuf)
-                     __attribute__((always_inline)) {
+    auto wait_lgkm = [&](int n) __attribute__((always_inline)) {          // n is a constant after unrolling
+        switch (n) {
+            case 15: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt lgkmcnt(13)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        }
+    };
+    // ---- transposed reads of P.K (B operand: keys column-wise).  They are inline asm: through the builtin hipcc orders every
+    // ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the tile ring.  Column tile c
+    // takes 4 reads (lo: k-step 0, hi: k-step 1) into buffer c % (PF+1); they are counted by hand (LDS returns in order).
+    // The state lives at function scope so that the pipelined loop can issue the FIRST PF column tiles of P.K(t) in the tail
+    // of the score product of tile t+1 (no pipeline-fill bubble between the two MFMA phases).
+#ifndef MOMA_K2_PF
+#define MOMA_K2_PF 2
+#endif
+    constexpr int PF = MOMA_K2_PF;                     // column tiles of transposed reads in flight
+    s16x4 kb[PF + 1][4];
+    unsigned ba[4][2];
+    auto pv_setup = [&](const char* buf) __attribute__((always_inline)) {
+        const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            ba[c4][0] = lbase + b_off[c4][0];
+            ba[c4][1] = lbase + b_off[c4][1];
+        }
+    };
+    auto issue_lo = [&](int c) __attribute__((always_inline)) {
+        s16x4* k4 = kb[c % (PF + 1)];
+        const int imm = (c >> 2) * 8192;
+        (void)imm;
+#ifndef MOMA_K2_ABL_NO_PV_LDS
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
+#else
+        asm volatile("" : "=v"(k4[0]), "=v"(k4[1]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
+#endif
+    };
+    auto issue_hi = [&](int c) __attribute__((always_inline)) {
+        s16x4* k4 = kb[c % (PF + 1)];
+        const int imm = (c >> 2) * 8192;
+        (void)imm;
+#ifndef MOMA_K2_ABL_NO_PV_LDS
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
+#else
+        asm volatile("" : "=v"(k4[2]), "=v"(k4[3]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
+#endif
+    };
+
+    // pvpre_tag (true_type): the last 2*PF gaps of the product also issue the first PF column tiles of the transposed reads of
+    // `pvbuf` (the tile P.K runs on next), two reads per gap; the product's own waits then count those younger reads too, and
+    // the s_nops behind the last MFMA are dropped (the caller keeps every VALU reader of x behind >= 4 further MFMAs).
+    auto score = [&](auto refill_tag, auto pvpre_tag, const char* buf, f32x16& x, float init, long rkey0, char* rbuf,
+                     const char* pvbuf) __attribute__((always_inline)) {
+        constexpr bool PVPRE = decltype(pvpre_tag)::value;
+        constexpr int NPRE = PVPRE ? 2 * PF : 0;                                  // gaps that carry a lo / hi pair
         // One wave per SIMD issues in order: what sits between two MFMAs runs in the shadow of the first (about 24
         // free issue cycles per 32-cycle MFMA; measured: one ds_read_b128 or one LDS-DMA piece per 4 hides fully),
         // while long runs of non-MFMA work idle the matrix pipe.  So each k-step is "one ds_read_b128 for k-step
@@ -333,25 +407,19 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         };
 #pragma unroll
         for (int ks = 0; ks < RD; ++ks) rd(ks);
+#ifdef MOMA_K2_DMA_FRONT
+        if constexpr (REFILL != 0) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dma_piece<D, REFILL == 2>(i, dl, queue, rkey0, K, rbuf, wave, lane);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            // reads ks+1 .. min(ks+RD-1, KS-1) may stay in flight
+            // reads ks+1 .. min(ks+RD-1, KS-1) may stay in flight, and the transposed reads issued so far in the tail
             const int ahead = (KS - 1 - ks) < (RD - 1) ? (KS - 1 - ks) : (RD - 1);
-            switch (ahead) {
-                case 11: asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory"); break;
-                case 10: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
-            }
+            const int pre = ks > KS - NPRE ? 2 * (ks - (KS - NPRE)) : 0;
+            wait_lgkm(ahead + pre);
             __builtin_amdgcn_sched_barrier(0);
             // inline-asm MFMA pins the score accumulator to VGPRs (through the builtin hipcc puts it in a[0:15] and
             // moves O's first column tile out and back every tile).  Hazards by hand: s_nop before the first MFMA
@@ -359,7 +427,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #ifndef MOMA_K2_ABL_NO_SCORE_MFMA
             if (ks == 0)
                 asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
-            else if (ks == KS - 1)
+            else if (ks == KS - 1 && !PVPRE)
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
             else
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
@@ -367,8 +435,17 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             asm volatile("" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
 #endif
             if (ks + RD < KS) rd(ks + RD);
+            if constexpr (PVPRE) {
+                static_assert(NPRE <= KS && PF <= NCT, "tail gaps and column tiles exist");
+                if (ks == KS - NPRE) pv_setup(pvbuf);
+                if (ks >= KS - NPRE) {
+                    const int j = ks - (KS - NPRE);                            // 0 .. 2*PF-1 : (column tile j/2, lo / hi)
+                    if ((j & 1) == 0) issue_lo(j >> 1);
+                    else issue_hi(j >> 1);
+                }
+            }
             if constexpr (REFILL != 0) {
-#ifndef MOMA_K2_ABL_NO_LOOP_DMA
+#if !defined(MOMA_K2_ABL_NO_LOOP_DMA) && !defined(MOMA_K2_DMA_FRONT)
                 if ((ks & 3) == 1) dma_piece<D, REFILL == 2>(ks >> 2, dl, queue, rkey0, K, rbuf, wave, lane);
 #endif
             }
@@ -379,9 +456,18 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     auto score_dispatch = [&](const char* buf, f32x16& x, float init, bool refill, int rtile) __attribute__((always_inline)) {
         const long rkey0 = (long)rtile * KT;
         char* rbuf = slot(rtile);
-        if (!refill) score(std::integral_constant<int, 0>{}, buf, x, init, rkey0, rbuf);
-        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, buf, x, init, rkey0, rbuf);
-        else score(std::integral_constant<int, 1>{}, buf, x, init, rkey0, rbuf);
+        if (!refill) score(std::integral_constant<int, 0>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
+        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
+        else score(std::integral_constant<int, 1>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
+    };
+    // the same with the first transposed reads of P.K on `pvbuf` issued in the product's tail (pipelined loop)
+    auto score_dispatch_pv = [&](const char* buf, f32x16& x, float init, bool refill, int rtile, const char* pvbuf)
+                                 __attribute__((always_inline)) {
+        const long rkey0 = (long)rtile * KT;
+        char* rbuf = slot(rtile);
+        if (!refill) score(std::integral_constant<int, 0>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
+        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
+        else score(std::integral_constant<int, 1>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
     };
     // keys past K (only in the queue's last tile) get -inf scores; key of register r = (r&3) + 8*(r>>2) + 4*h
     auto mask_tail = [&](f32x16& x, int t) __attribute__((always_inline)) {
@@ -424,50 +510,20 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         }
         l_run += psum;
     };
-    // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols].  The transposed reads are inline asm: through the builtin
-    // hipcc orders every ds_read_b64_tr_b16 behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain
-    // the tile ring.  They are counted by hand: fragments of column tile c+PF are requested before tile c's MFMAs,
-    // so "tile c has arrived" is lgkmcnt(4*PF) (LDS returns in order).  `between(c)` is executed in the shadow of
-    // column tile c's two MFMAs (the pipelined loop puts one step of the NEXT tile's softmax there).
+    // ---- O[q, cols] += P[q, keys] . K_tile[keys, cols].  Fragments of column tile c+PF are requested before tile c's
+    // MFMAs, so "tile c has arrived" is lgkmcnt(4*PF).  `between(c)` is executed in the shadow of column tile c's two MFMAs
+    // (the pipelined loop puts the NEXT tile's softmax there).  prefetched_tag: the first PF column tiles were already requested
+    // by the preceding score product (score_dispatch_pv).
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto pv = [&](const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
+    auto pv = [&](auto prefetched_tag, const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
         if constexpr (WITH_DQ) {
-#ifndef MOMA_K2_PF
-#define MOMA_K2_PF 3
-#endif
-            constexpr int PF = MOMA_K2_PF;                     // column tiles of transposed reads in flight
-            const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
-            unsigned ba[4][2];
+            if constexpr (!decltype(prefetched_tag)::value) {
+                pv_setup(buf);
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                ba[c4][0] = lbase + b_off[c4][0];
-                ba[c4][1] = lbase + b_off[c4][1];
-            }
-            s16x4 kb[PF + 1][4];
-            auto issue_lo = [&](int c) __attribute__((always_inline)) {
-                s16x4* k4 = kb[c % (PF + 1)];
-                const int imm = (c >> 2) * 8192;
-#ifndef MOMA_K2_ABL_NO_PV_LDS
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
-#else
-                asm volatile("" : "=v"(k4[0]), "=v"(k4[1]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
-#endif
-            };
-            auto issue_hi = [&](int c) __attribute__((always_inline)) {
-                s16x4* k4 = kb[c % (PF + 1)];
-                const int imm = (c >> 2) * 8192;
-#ifndef MOMA_K2_ABL_NO_PV_LDS
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
-#else
-                asm volatile("" : "=v"(k4[2]), "=v"(k4[3]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
-#endif
-            };
-#pragma unroll
-            for (int c = 0; c < PF; ++c) {
-                issue_lo(c);
-                issue_hi(c);
+                for (int c = 0; c < PF; ++c) {
+                    issue_lo(c);
+                    issue_hi(c);
+                }
             }
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -550,13 +606,15 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     mx = NEG_BIG;
     ovf = 0;
     // Q and tile t0 have landed (the rest of the ring stays in flight); from here on the Q registers may be read
+    if constexpr (!repass) K2_STAMP(10, 9);
     wait_tiles_in_flight(min(npro, PRO) - 1);
+    if constexpr (!repass) K2_STAMP(-1, 10);
     if constexpr (MODE != 2) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
     __builtin_amdgcn_s_barrier();
-    if constexpr (PRO < NBUF) issue_ring(std::false_type{}, PRO, NBUF);
+    if constexpr (PRO < NBUF && !PIPELINED) issue_ring(std::false_type{}, PRO, NBUF);
     if constexpr (!repass) K2_STAMP(-1, 3);
     if constexpr (!repass) K2_STAMP(4, -1);
 
@@ -567,11 +625,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // Live ring slots: t, t+1 ; in flight: t+2, t+3.
         f32x16 xa;
         bf16x8 pa[2];
-        score_dispatch(slot(t0), xa, 0.f, false, t0);
+        score_dispatch(slot(t0), xa, 0.f, t0 + 2 < t1, t0 + 2);          // (tile t0+2 requested in its shadow)
         softmax_plain(xa, t0, !repass);
         pack(xa, pa);
-        // tile t0+1 must have landed before the loop's first score
-        wait_tiles_in_flight(max(min(t0 + NBUF - 1, t1 - 1) - (t0 + 1), 0));
+        // tile t0+1 must have landed before the loop's first score (t0+2 may stay in flight)
+        wait_tiles_in_flight(max(min(t0 + 2, t1 - 1) - (t0 + 1), 0));
         __builtin_amdgcn_s_barrier();
         if constexpr (!repass) K2_STAMP(-1, 4);
         if constexpr (!repass) K2_STAMP(5, -1);
@@ -588,39 +646,41 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             K2_STAMP(0, -1);
 #endif
             {
-                // the slot of tile t-1 (free since the barrier that ended iteration t-1) takes tile t+NBUF-1
-                const bool refill = t >= t0 + 1 && t + NBUF - 1 < t1;
-                score_dispatch(slot(t + 1), xb, -m_ref, refill, t + NBUF - 1);
-                mask_tail(xb, t + 1);
+                // the slot of tile t-1 (free since the barrier that ended iteration t-1; never used yet at t = t0) takes tile t+NBUF-1;
+                // the product's tail already requests the first column tiles of P.K(t): the two MFMA phases run back to back
+                const bool refill = t + NBUF - 1 < t1;
+                score_dispatch_pv(slot(t + 1), xb, -m_ref, refill, t + NBUF - 1, slot(t));
             }
 #if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
             K2_STAMP(1, 0);
 #endif
             float tmax = NEG_BIG, psum = 0.f;
-            pv(slot(t), pa, [&](int c) __attribute__((always_inline)) {
+            // One softmax step (register j of the score tile: running max, 2^x, running sum) per P.K column tile.  xb holds
+            // score - m_ref.  The exponential and the sum are inline asm: as plain expressions hipcc sinks them to their use
+            // BEHIND the 2*NCT MFMAs of P.K; volatile statements stay between the transposed reads of their column tile.  The
+            // sum lags one step (no instruction reads a transcendental result right behind its v_exp_f32).  The steps start
+            // SM_SHIFT column tiles into P.K: the score MFMAs were issued without trailing wait states, and no VALU may read
+            // their accumulator before >= 4 further MFMAs have gone by.
+            constexpr int SM_SHIFT = 2;
+            auto sm_step = [&](int j) __attribute__((always_inline)) {
 #ifndef MOMA_K2_ABL_NO_SOFTMAX
-                // xb already holds score - m_ref.  The exponential and the running sum are inline asm: as plain
-                // expressions hipcc sinks them to their use BEHIND the 2*NCT MFMAs of P.K (~100 issue slots that then idle
-                // the matrix pipe); volatile statements stay between the transposed reads of their column tile.  The sum
-                // lags one step, so no instruction reads a transcendental result right behind its v_exp_f32.
-                if (c < 16) {
-                    tmax = fmaxf(tmax, xb[c]);
-                    asm volatile("v_exp_f32 %0, %0" : "+v"(xb[c]));
-                    if (c >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[c - 1]));
-                }
+                tmax = fmaxf(tmax, xb[j]);
+                asm volatile("v_exp_f32 %0, %0" : "+v"(xb[j]));
+                if (j >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[j - 1]));
 #endif
+            };
+            pv(std::true_type{}, slot(t), pa, [&](int c) __attribute__((always_inline)) {
+                if (c == SM_SHIFT) mask_tail(xb, t + 1);
+                if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step(c - SM_SHIFT);
             });
-#ifndef MOMA_K2_ABL_NO_SOFTMAX
-            psum += xb[(NCT < 16 ? NCT : 16) - 1];
-#endif
-            if constexpr (NCT < 16) {
 #pragma unroll
-                for (int c = NCT; c < 16; ++c) {
-                    tmax = fmaxf(tmax, xb[c]);
-                    xb[c] = __builtin_amdgcn_exp2f(xb[c]);
-                    psum += xb[c];
-                }
+            for (int j = (NCT > SM_SHIFT ? NCT - SM_SHIFT : 0); j < 16; ++j) {
+                if (NCT <= SM_SHIFT && j == 0) mask_tail(xb, t + 1);
+                sm_step(j);
             }
+#ifndef MOMA_K2_ABL_NO_SOFTMAX
+            psum += xb[15];
+#endif
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));       // relative to m_ref
             ovf |= (tmax > OVERFLOW_THR) ? 1 : 0;
             mx = fmaxf(mx, tmax + m_ref);                       // back to absolute log2 units
@@ -630,11 +690,15 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             K2_STAMP(2, 1);
 #endif
             // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
+#ifndef MOMA_K2_ABL_NO_DMA_WAIT
             {
                 const int newest = min(t + NBUF - 1, t1 - 1);
                 wait_tiles_in_flight(newest - (t + 2) > 0 ? newest - (t + 2) : 0);
             }
+#endif
+#ifndef MOMA_K2_ABL_NO_LOOP_BARRIER
             __builtin_amdgcn_s_barrier();
+#endif
 #if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
             K2_STAMP(-1, 2);
 #endif
@@ -646,7 +710,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
         {
             uint4* dst = opart_dst();
-            pv(slot(t1 - 1), pa, [&](int c) __attribute__((always_inline)) {
+            pv(std::false_type{}, slot(t1 - 1), pa, [&](int c) __attribute__((always_inline)) {
                 if (c >= 1) store_tile(dst, c - 1);
             });
             store_tile(dst, NCT - 1);
@@ -683,7 +747,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                     for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);      // m_ref = the row's lse (log2)
                     bf16x8 pa[2];
                     pack(x, pa);
-                    pv(slot(t), pa, [&](int) __attribute__((always_inline)) {});
+                    pv(std::false_type{}, slot(t), pa, [&](int) __attribute__((always_inline)) {});
                 }
             } else {
                 f32x16 x;
@@ -728,7 +792,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #ifdef MOMA_K2_STAMPS
     if constexpr (PIPELINED) {
         K2_STAMP(-1, 6);
-        if (lane < 8) moma_k2_stamps[((blockIdx.x * 4 + wave) & 1023) * 8 + lane] = reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 8 + lane];
+        if (lane < 16) moma_k2_stamps[((blockIdx.x * 4 + wave) & 1023) * 16 + lane] = reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 16 + lane];
     }
 #endif
 }
