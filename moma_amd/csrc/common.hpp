@@ -23,6 +23,14 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
     return *reinterpret_cast<bf16_raw*>(&b);
 }
 
+// value of lane l ^ 32 (the other half of the wave) by one v_permlane32_swap -- a VALU instruction; __shfl_xor(v, 32) is a
+// ds_bpermute, i.e. an LDS round trip with a wait
+__device__ __forceinline__ float other_half(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = {lo, lo}, r[1] = {hi, hi}
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -286,22 +286,17 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 
     // per-lane LDS offsets
     //  row read (A operand of the score MFMA): key row n, chunk 2*(ks&7)+h of segment ks>>3
-    int a_off[8];
-    {
-        const int g = swz(n) ^ h;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a_off[c] = n * 256 + (((2 * c) ^ g) << 4);
-    }
+    //  chunk (2c ^ g) of the row = lane part ^ (c << 5): ONE register across tiles, the 8 addresses of a tile are xor-ed from it
+    //  when the tile begins (tile slots are 8 KiB-aligned, so bits 4..7 of the lane part belong to the chunk alone).  An xor in
+    //  front of every read instead (one address register in all) costs 4 us: the reads then wait on the VALU result.
+    const int a_off = n * 256 + ((swz(n) ^ h) << 4);
     //  transposed read (B operand of P.K): 16-lane group -> 4 keys x 16 columns
-    int b_off[4][2];
+    //  chunk ((c ^ q4) << 2 | (e ^ 2u)) = lane part ^ (c << 6) ^ (u << 5), same scheme
+    int b_off;
     {
         const int i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
         const int e = (2 * g2 + (p >> 1)) ^ h;
-        const int base = (4 * h + q4) * 256 + 8 * (p & 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) b_off[c][u] = base + (((((c ^ q4) << 2) | (e ^ (2 * u)))) << 4);
+        b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
     }
 
     // ---- scores of one tile: X[key, q] over D.  A fragments (keys) are requested RD k-steps ahead
@@ -309,6 +304,9 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // reads behind the MFMAs and exposes the LDS latency once per group).  One LDS-DMA piece of the refill tile is
     // issued after every 4th MFMA, so its issue cost hides behind the matrix pipe.
     auto wait_lgkm = [&](int n) __attribute__((always_inline)) {          // n is a constant after unrolling
+#ifdef MOMA_K2_ABL_NO_LGKM_SCORE
+        return;                                                          // (timing experiment only: results are garbage)
+#endif
         switch (n) {
             case 15: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
             case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
@@ -333,6 +331,9 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // takes 4 reads (lo: k-step 0, hi: k-step 1) into buffer c % (PF+1); they are counted by hand (LDS returns in order).
     // The state lives at function scope so that the pipelined loop can issue the FIRST PF column tiles of P.K(t) in the tail
     // of the score product of tile t+1 (no pipeline-fill bubble between the two MFMA phases).
+#ifndef MOMA_K2_ROT
+#define MOMA_K2_ROT 1          // pipelined loop: next tile's first A fragments requested behind the end-of-iteration barrier
+#endif
 #ifndef MOMA_K2_PF
 #define MOMA_K2_PF 2
 #endif
@@ -340,11 +341,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     s16x4 kb[PF + 1][4];
     unsigned ba[4][2];
     auto pv_setup = [&](const char* buf) __attribute__((always_inline)) {
-        const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
+        const unsigned b0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + b_off;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            ba[c4][0] = lbase + b_off[c4][0];
-            ba[c4][1] = lbase + b_off[c4][1];
+            ba[c4][0] = b0 ^ (c4 << 6);
+            ba[c4][1] = b0 ^ ((c4 << 6) | 32);
         }
     };
     auto issue_lo = [&](int c) __attribute__((always_inline)) {
@@ -373,40 +374,55 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // pvpre_tag (true_type): the last 2*PF gaps of the product also issue the first PF column tiles of the transposed reads of
     // `pvbuf` (the tile P.K runs on next), two reads per gap; the product's own waits then count those younger reads too, and
     // the s_nops behind the last MFMA are dropped (the caller keeps every VALU reader of x behind >= 4 further MFMAs).
-    auto score = [&](auto refill_tag, auto pvpre_tag, const char* buf, f32x16& x, float init, long rkey0, char* rbuf,
-                     const char* pvbuf) __attribute__((always_inline)) {
+#ifndef MOMA_K2_RD
+#define MOMA_K2_RD 4      // (with the rotated loop the first fragments are early anyway; 6 and 8 spill at D = 512)
+#endif
+    constexpr int RD = MOMA_K2_RD < KS ? MOMA_K2_RD : KS;                             // LDS read distance in k-steps (RD x 32 cycles)
+    static_assert(RD <= 12 && RD <= KS, "lgkmcnt is a 4-bit counter");
+    // A fragments of the score product (keys, row-wise): a ring of RD k-steps, requested by inline asm and counted by hand
+    // (hipcc's own waits were lgkmcnt(0) every 8 steps: the latency of the newest read exposed 4x per tile).  `score_begin`
+    // requests the first RD k-steps of a tile; the pipelined loop calls it for the NEXT iteration's tile right behind the barrier
+    // that makes the tile visible, so the LDS latency of the first fragments passes under the end-of-iteration bookkeeping.
+    f32x4 kf[RD];
+    unsigned aa[8];
+    auto rd = [&](int ks) __attribute__((always_inline)) {
+#ifndef MOMA_K2_ABL_NO_SCORE_LDS
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");
+#else
+        asm volatile("" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]));
+#endif
+    };
+    auto score_begin = [&](const char* buf) __attribute__((always_inline)) {
+        const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) aa[c] = a0 ^ (c << 5);
+#pragma unroll
+        for (int ks = 0; ks < RD; ++ks) rd(ks);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // pvpre_tag (true_type): the last 2*PF gaps of the product also issue the first PF column tiles of the transposed reads of
+    // `pvbuf` (the tile P.K runs on next), two reads per gap; the product's own waits then count those younger reads too, and
+    // the s_nops behind the last MFMA are dropped (the caller keeps every VALU reader of x behind >= 4 further MFMAs).
+    // begun_tag (true_type): score_begin(buf) was already called for this tile.
+    auto score = [&](auto refill_tag, auto pvpre_tag, auto begun_tag, const char* buf, f32x16& x, float init, long rkey0,
+                     char* rbuf, const char* pvbuf) __attribute__((always_inline)) {
         constexpr bool PVPRE = decltype(pvpre_tag)::value;
         constexpr int NPRE = PVPRE ? 2 * PF : 0;                                  // gaps that carry a lo / hi pair
         // One wave per SIMD issues in order: what sits between two MFMAs runs in the shadow of the first (about 24
         // free issue cycles per 32-cycle MFMA; measured: one ds_read_b128 or one LDS-DMA piece per 4 hides fully),
         // while long runs of non-MFMA work idle the matrix pipe.  So each k-step is "one ds_read_b128 for k-step
-        // ks+RD, [one DMA piece every 4th step], one MFMA", in exactly that order (sched_barriers).  The reads are
-        // inline asm counted by hand: hipcc's own waits were lgkmcnt(0) every 8 steps (the latency of the newest read
-        // exposed 4x per tile).  x starts at -m_ref ("row constant as the initial accumulator"): no subtraction later.
+        // ks+RD, [one DMA piece every 4th step], one MFMA", in exactly that order (sched_barriers).
+        // x starts at -m_ref ("row constant as the initial accumulator"): no subtraction later.
         // refill_tag: 0 = no refill, 1 = refill with a full tile, 2 = refill with the queue's last (partial) tile.
         constexpr int REFILL = decltype(refill_tag)::value;
-#ifndef MOMA_K2_RD
-#define MOMA_K2_RD 8
-#endif
-        constexpr int RD = MOMA_K2_RD < KS ? MOMA_K2_RD : KS;                         // LDS read distance in k-steps (RD x 32 cycles)
         static_assert(KS % 4 == 0 && KS / 4 == PPW, "one DMA piece per 4 k-steps");
+        if constexpr (!decltype(begun_tag)::value) score_begin(buf);
+        // the first MFMA takes the row constant as a separate C tuple (loop-invariant registers; copying it into x first was 8
+        // v_mov_b64 per tile at the top of the product, where nothing overlaps them)
+        f32x16 c0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = init;
-        const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf;
-        unsigned aa[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) aa[c] = lbase + a_off[c];
-        static_assert(RD <= 12 && RD <= KS, "lgkmcnt is a 4-bit counter");
-        f32x4 kf[RD];
-        auto rd = [&](int ks) __attribute__((always_inline)) {
-#ifndef MOMA_K2_ABL_NO_SCORE_LDS
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");
-#else
-            asm volatile("" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]));
-#endif
-        };
-#pragma unroll
-        for (int ks = 0; ks < RD; ++ks) rd(ks);
+        for (int r = 0; r < 16; ++r) c0[r] = init;
 #ifdef MOMA_K2_DMA_FRONT
         if constexpr (REFILL != 0) {
 #pragma unroll
@@ -426,13 +442,14 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // (VALU-written C), s_nops after the last one (VALU readers of D).
 #ifndef MOMA_K2_ABL_NO_SCORE_MFMA
             if (ks == 0)
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "v"(c0));
             else if (ks == KS - 1 && !PVPRE)
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
             else
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
 #else
-            asm volatile("" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
+            if (ks == 0) asm volatile("" : "=&v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "v"(c0));
+            else asm volatile("" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
 #endif
             if (ks + RD < KS) rd(ks + RD);
             if constexpr (PVPRE) {
@@ -456,18 +473,21 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     auto score_dispatch = [&](const char* buf, f32x16& x, float init, bool refill, int rtile) __attribute__((always_inline)) {
         const long rkey0 = (long)rtile * KT;
         char* rbuf = slot(rtile);
-        if (!refill) score(std::integral_constant<int, 0>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
-        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
-        else score(std::integral_constant<int, 1>{}, std::false_type{}, buf, x, init, rkey0, rbuf, nullptr);
+        constexpr std::false_type F{};
+        if (!refill) score(std::integral_constant<int, 0>{}, F, F, buf, x, init, rkey0, rbuf, nullptr);
+        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, F, F, buf, x, init, rkey0, rbuf, nullptr);
+        else score(std::integral_constant<int, 1>{}, F, F, buf, x, init, rkey0, rbuf, nullptr);
     };
-    // the same with the first transposed reads of P.K on `pvbuf` issued in the product's tail (pipelined loop)
+    // pipelined loop: first A fragments already requested (score_begin), first transposed reads of P.K on `pvbuf` in the tail
     auto score_dispatch_pv = [&](const char* buf, f32x16& x, float init, bool refill, int rtile, const char* pvbuf)
                                  __attribute__((always_inline)) {
         const long rkey0 = (long)rtile * KT;
         char* rbuf = slot(rtile);
-        if (!refill) score(std::integral_constant<int, 0>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
-        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
-        else score(std::integral_constant<int, 1>{}, std::true_type{}, buf, x, init, rkey0, rbuf, pvbuf);
+        constexpr std::true_type T{};
+        constexpr std::integral_constant<bool, (MOMA_K2_ROT != 0)> R{};
+        if (!refill) score(std::integral_constant<int, 0>{}, T, R, buf, x, init, rkey0, rbuf, pvbuf);
+        else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, T, R, buf, x, init, rkey0, rbuf, pvbuf);
+        else score(std::integral_constant<int, 1>{}, T, R, buf, x, init, rkey0, rbuf, pvbuf);
     };
     // keys past K (only in the queue's last tile) get -inf scores; key of register r = (r&3) + 8*(r>>2) + 4*h
     auto mask_tail = [&](f32x16& x, int t) __attribute__((always_inline)) {
@@ -492,7 +512,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         float tmax = x[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, other_half(tmax));
         mx = fmaxf(mx, tmax);
         if (first) {
             m_ref = tmax + REF_MARGIN;
@@ -529,10 +549,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             for (int c = 0; c < NCT; ++c) {
                 // in flight when tile c's first MFMA issues: all of c+1 .. c+PF-1, nothing of c+PF yet
                 const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
+#ifndef MOMA_K2_ABL_NO_LGKM_PV                                     // (defined: timing experiment only, results are garbage)
                 if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
                 else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 s16x4* k4 = kb[c % (PF + 1)];
                 const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -639,6 +661,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #else
         const int tlast = t1 - 1;
 #endif
+        if (MOMA_K2_ROT && t0 < tlast) score_begin(slot(t0 + 1));            // first A fragments of the loop's first score product
 #pragma unroll 1
         for (int t = t0; t < tlast; ++t) {
             f32x16 xb;
@@ -664,8 +687,8 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             constexpr int SM_SHIFT = 2;
             auto sm_step = [&](int j) __attribute__((always_inline)) {
 #ifndef MOMA_K2_ABL_NO_SOFTMAX
-                tmax = fmaxf(tmax, xb[j]);
-                asm volatile("v_exp_f32 %0, %0" : "+v"(xb[j]));
+                asm volatile("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(xb[j]));       // (pinned here: left to hipcc the maxima sink
+                asm volatile("v_exp_f32 %0, %0" : "+v"(xb[j]));                       //  behind the barrier and every x is copied first)
                 if (j >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[j - 1]));
 #endif
             };
@@ -681,24 +704,26 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #ifndef MOMA_K2_ABL_NO_SOFTMAX
             psum += xb[15];
 #endif
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));       // relative to m_ref
-            ovf |= (tmax > OVERFLOW_THR) ? 1 : 0;
-            mx = fmaxf(mx, tmax + m_ref);                       // back to absolute log2 units
-            l_run += psum;
-            pack(xb, pa);
 #if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
             K2_STAMP(2, 1);
 #endif
             // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
 #ifndef MOMA_K2_ABL_NO_DMA_WAIT
-            {
-                const int newest = min(t + NBUF - 1, t1 - 1);
-                wait_tiles_in_flight(newest - (t + 2) > 0 ? newest - (t + 2) : 0);
-            }
+            if (t + NBUF - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");     // (one two-way branch, not the general switch)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #ifndef MOMA_K2_ABL_NO_LOOP_BARRIER
             __builtin_amdgcn_s_barrier();
 #endif
+            // the next iteration's first A fragments are requested right here, and the bookkeeping of THIS tile runs under
+            // their LDS latency: per-lane-half statistics (tmax is relative to m_ref; the two halves of a row are merged once
+            // after the loop -- a cross-half shuffle here would be an LDS round trip on the critical path of every tile) and
+            // the bf16 packing of P(t+1)
+            if constexpr (MOMA_K2_ROT) score_begin(slot(t + 2));       // (unconditional: behind the loop's last iteration the fragments are simply not used)
+            ovf |= (tmax > OVERFLOW_THR) ? 1 : 0;
+            mx = fmaxf(mx, tmax + m_ref);                       // back to absolute log2 units
+            l_run += psum;
+            pack(xb, pa);
 #if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
             K2_STAMP(-1, 2);
 #endif
@@ -762,6 +787,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 
     };
     run_pass(std::false_type{});
+    mx = fmaxf(mx, other_half(mx));                                              // (the loop keeps per-half maxima)
     if constexpr (PIPELINED) {
         int* wflag = reinterpret_cast<int*>(smem + NBUF * TILE_BYTES);         // 4 words behind the ring
         const int any = __any(ovf) ? 1 : 0;
@@ -771,11 +797,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             m_ref = mx;                                                          // true row maxima of the chunk
             __syncthreads();                                                     // flags read before the ring is refilled
             run_pass(std::true_type{});
+            mx = fmaxf(mx, other_half(mx));
         }
     }
 
     // ---- partials per (chunk, query row): m, l, true max ; O[chunk][row][D] (relative to m)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + other_half(l_run);
     if (MODE == 0 && h == 0) {
         m_part[prow + n] = m_ref;
         l_part[prow + n] = l_tot;
