@@ -60,6 +60,10 @@ extern "C" int moma_debug_read_stamps(unsigned* host) {
 #define K2_STAMP(neg, pos) do { } while (0)
 #endif
 
+#ifndef MOMA_K2_WIDE_NRW
+#define MOMA_K2_WIDE_NRW 2      // row-waves per workgroup of the wide P.K pass (2: a key tile serves 64 query rows)
+#endif
+
 namespace moma {
 namespace {
 
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
 //   `queue` then points at the slab's first column and `slab` carries the row pitch and the first-slab flag.
 struct SlabArgs {
     float* xs;
-    const float* lse;     // [B] natural-log lse of the complete logits (MODE 2)
+    const float* lse;     // [B] natural-log lse of the complete logits (MODE 2, normalised P) -- or
+    const float* mref;    // [nchunk][Bpad] log2 reference per (chunk, row) (MODE 2, P = 2^(x - mref): the combine kernel weighs)
     unsigned pitch;       // bytes between queue rows
     int first;            // MODE 1: this is the first slab (store instead of accumulate)
 };
@@ -216,7 +221,24 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
 
     float m_ref = NEG_BIG;
-    if constexpr (MODE == 2) m_ref = slab.lse[min(bt * QROWS_WG + wave * 32 + n, B - 1)] * 1.4426950408889634f;
+    if constexpr (MODE == 2)
+        m_ref = slab.mref ? slab.mref[prow + n] : slab.lse[min(bt * QROWS_WG + wave * 32 + n, B - 1)] * 1.4426950408889634f;
+    // MODE 2: the finished scores of tile t are loaded one tile ahead by inline asm (counted by hand like the Q loads: at the
+    // first use of an ordinary load hipcc drains vmcnt to 0, the whole tile ring included, and the load's own latency -- a
+    // round trip to the scratch in HBM / Infinity Cache -- was exposed once per tile)
+    f32x16 xnext;
+    auto load_scores = [&](int t) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+            const char* xa = reinterpret_cast<const char*>(slab.xs + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 16);
+            f32x4 v0, v1, v2, v3;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(xa) : "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { xnext[r] = v0[r]; xnext[4 + r] = v1[r]; xnext[8 + r] = v2[r]; xnext[12 + r] = v3[r]; }
+        }
+    };
+    if constexpr (MODE == 2) load_scores(t0);       // (older than every tile of the ring: landed with the prologue's first wait)
 
     // ---- Q fragments: B operand of X = K.Q^T ; lane (q=n, h) holds Q[q][16ks + 8h + j], pre-scaled by log2e/T,
     //      pre-packed in fragment order by infonce_qpack_kernel (coalesced 16 B per lane).  The loads are inline asm and
@@ -761,12 +783,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) xa[g4] = make_float4(x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]);
                 } else {
+                    asm volatile("" : "+v"(xnext));                          // (landed: the wait at the end of the last iteration)
+                    x = xnext;
+                    if (t + 1 < t1) load_scores(t + 1);                      // older than this iteration's refill pieces
                     if (refill) dma_tile<D>(dl, queue, (long)(t + NBUF - 1) * KT, K, slot(t + NBUF - 1), wave, lane);
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 v = xa[g4];
-                        x[4 * g4] = v.x; x[4 * g4 + 1] = v.y; x[4 * g4 + 2] = v.z; x[4 * g4 + 3] = v.w;
-                    }
                     mask_tail(x, t);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);      // m_ref = the row's lse (log2)
@@ -780,6 +800,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 softmax_plain(x, t, t == t0);
             }
             // tile t+1 must have landed (tiles t+2.. may stay in flight); every wave must be done with this slot
+            if constexpr (MODE == 2) {
+                // ... and the scores of tile t+1: only this iteration's refill pieces are younger than they are
+                if (refill) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else
             wait_tiles_in_flight(max(min(t + NBUF - 1, t1 - 1) - (t + 1), 0));
             __builtin_amdgcn_s_barrier();
         }
@@ -845,18 +870,442 @@ __global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __res
                                            o_part, nullptr, nullptr, nullptr, slab);
 }
 
+// ---- wide queues, scores in ONE pass (d = NSEG x 128 columns, 512 < d <= 1536) ---------------------------------------------
+// The score product needs no O accumulator, so the whole 32 x d Q block of a wave fits the register file as the B operand:
+// the first 64 fragments (1024 columns) in the 256 AGPRs, the rest in VGPRs (MFMA A/B operands may be AGPRs).  A key tile
+// (32 keys x d, up to 96 KiB) does not fit a ring, so the LDS-DMA unit is a PHASE of PSEG segments (32 keys x PSEG*128 columns,
+// 3 phase buffers): x accumulates over the NSEG/PSEG phases of a tile; behind the tile's last phase the wave updates its
+// online (max, sum) per lane half and stores the complete fp32 scores in register order (the P.K slab passes read them).
+// Leaves per (chunk, row): m = true maximum, l = sum 2^(x - m), max = m -- the partial format of the one-pass kernel.
+template <int NSEG, int PSEG>
+__global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4* __restrict__ qpack,
+                                                                     const bf16_raw* __restrict__ queue, int B, int K, int nbt,
+                                                                     int nchunk, int tiles_per_chunk, int Bpad,
+                                                                     float* __restrict__ xs, float* __restrict__ m_part,
+                                                                     float* __restrict__ l_part, float* __restrict__ x_part) {
+    static_assert(NSEG % PSEG == 0 && PSEG <= 6, "phases tile the row; 3 phase buffers fit 160 KiB");
+    constexpr int KS = NSEG * 8;                    // k-steps of a complete score tile
+    constexpr int NA = KS < 64 ? KS : 64;           // Q fragments kept in AGPRs
+    constexpr int NV = KS - NA;                     // ... and in VGPRs
+    constexpr int NPH = NSEG / PSEG;                // phases per key tile
+    constexpr int PSTEPS = PSEG * 8;                // k-steps per phase
+    constexpr int PPP = PSEG * 2;                   // LDS-DMA pieces per wave and phase
+    constexpr int PH_BYTES = PSEG * 8192;
+    constexpr int RD = 4;                           // A fragments in flight
+    static_assert(NV <= 32 && PSTEPS % 4 == 0 && PPP == PSTEPS / 4, "one DMA piece per 4 k-steps");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    int bt, chunk;
+    {
+        const int id = blockIdx.x;
+        if ((nchunk & 7) == 0) {
+            const int g = id / (8 * nbt), r = id % (8 * nbt);
+            bt = r >> 3;
+            chunk = g * 8 + (r & 7);
+        } else {
+            bt = id % nbt;
+            chunk = id / nbt;
+        }
+    }
+    const int ntiles = (K + KT - 1) / KT;
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(t0 + tiles_per_chunk, ntiles);
+    const unsigned pitch = NSEG * 256;
+    const DmaLane dl = dma_lane_terms<128>(lane, wave, pitch);
+    const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
+
+    // ---- Q: inline-asm loads (counted by hand: LDS-DMA and ordinary loads share vmcnt), AGPR part first
+    bf16x8 qa[NA];
+    bf16x8 qv[NV > 0 ? NV : 1];
+    {
+        const char* qb = reinterpret_cast<const char*>(qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane);
+#pragma unroll
+        for (int f = 0; f < KS; ++f) {
+            if (f < NA)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(qa[f < NA ? f : 0]) : "v"(qb + (f >> 2) * 4096), "n"((f & 3) * 1024) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[f >= NA ? f - NA : 0]) : "v"(qb + (f >> 2) * 4096), "n"((f & 3) * 1024) : "memory");
+        }
+    }
+    // ---- LDS-DMA of phase (tile, p) into a phase buffer: piece i of this wave = segment i>>1, row group (i&1)*4 + wave
+    auto dma_piece_ph = [&](int i, int tile, int p, char* buf) __attribute__((always_inline)) {
+        const int sg = i >> 1, rg = (i & 1) * 4 + wave;
+        const long key0 = (long)tile * KT;
+        const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (p * PSEG + sg) * 256;
+        unsigned off = dl.term;
+        if (key0 + KT > K) {                        // queue's last, partial tile: clamp rows past K (masked later)
+            const int rl = lane >> 4;
+            const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
+            off = off - (unsigned)rl * pitch + (unsigned)row * pitch;
+        } else {
+            src += rg * 4 * (long)pitch;
+        }
+        char* dst = buf + sg * 8192 + rg * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // global phase index g = (tile - t0) * NPH + p lives in buffer g % 3
+    const int nph_total = (t1 - t0) * NPH;
+    {
+        // phases 0 and 1 up front
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g < nph_total) {
+#pragma unroll
+                for (int i = 0; i < PPP; ++i) dma_piece_ph(i, t0 + g / NPH, g % NPH, smem + g * PH_BYTES);
+            }
+        }
+    }
+    const int a_off = n * 256 + ((swz(n) ^ h) << 4);
+    f32x4 kf[RD];
+    unsigned aa[8];
+    auto rd = [&](int j) __attribute__((always_inline)) {           // k-step j of the phase
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[j % RD]) : "v"(aa[j & 7]), "i"((j >> 3) * 8192) : "memory");
+    };
+    auto wait_lgkm = [&](int c) __attribute__((always_inline)) {
+        switch (c) {
+            case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        }
+    };
+    float m_run = NEG_BIG, l_run = 0.f;
+    // Q and phase 0 have landed (phase 1 may stay in flight)
+    if (nph_total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < NA; ++f) asm volatile("" : "+a"(qa[f]));
+#pragma unroll
+    for (int f = 0; f < NV; ++f) asm volatile("" : "+v"(qv[f]));
+    __builtin_amdgcn_s_barrier();
+
+    int bi = 0;                                      // buffer of the current phase
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        f32x16 x;
+#pragma unroll
+        for (int p = 0; p < NPH; ++p) {
+            const char* buf = smem + bi * PH_BYTES;
+            const int bfree = bi == 0 ? 2 : bi - 1;  // buffer of the previous phase: free since the last barrier
+            char* rbuf = smem + bfree * PH_BYTES;
+            const int rt = t + (p + 2) / NPH, rp = (p + 2) % NPH;
+            const bool refill = rt < t1;
+            {
+                const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) aa[c] = a0 ^ (c << 5);
+            }
+#pragma unroll
+            for (int j = 0; j < RD; ++j) rd(j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < PSTEPS; ++j) {
+                const int f = p * PSTEPS + j;
+                const int ahead = (PSTEPS - 1 - j) < (RD - 1) ? (PSTEPS - 1 - j) : (RD - 1);
+                wait_lgkm(ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                if (f == 0)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(x) : "v"(kf[j % RD]), "a"(qa[0]));
+                else if (f < NA)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[j % RD]), "a"(qa[f < NA ? f : 0]));
+                else
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[j % RD]), "v"(qv[f >= NA ? f - NA : 0]));
+                if (j + RD < PSTEPS) rd(j + RD);
+                if ((j & 3) == 1 && refill) dma_piece_ph(j >> 2, rt, rp, rbuf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (p == NPH - 1) {
+                // ---- the tile's scores are complete (the MFMA result needs its wait states before a VALU reads it)
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x));
+                if ((t + 1) * KT > K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
+                }
+                float4* xa = reinterpret_cast<float4*>(xs + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 16);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) xa[g4] = make_float4(x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]);
+                float tm = x[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, x[r]);
+                const float mn = fmaxf(m_run, tm);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(x[r] - mn);
+                l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + ps;
+                m_run = mn;
+            }
+            // the next phase must have landed.  Certainly younger than its pieces: this phase's refill pieces and, behind a tile's
+            // last phase, the 4 score stores just issued (the previous tile's stores may be younger too: not counted, i.e.
+            // waited for -- they are a phase old)
+            if (refill) {
+                if (p == NPH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP + 4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            bi = bi == 2 ? 0 : bi + 1;
+        }
+    }
+    // ---- per (chunk, row): the two lane halves hold disjoint keys of the same row
+    const float mo = other_half(m_run), lo = other_half(l_run);
+    const float M = fmaxf(m_run, mo);
+    const float L = l_run * __builtin_amdgcn_exp2f(m_run - M) + lo * __builtin_amdgcn_exp2f(mo - M);
+    if (h == 0) {
+        m_part[prow + n] = M;
+        l_part[prow + n] = L;
+        x_part[prow + n] = M;
+    }
+}
+
+// ---- wide queues, P.K in ONE pass over all columns (the scores are read ONCE) --------------------------------------------------
+// Workgroup = NRW row-waves (32 query rows each) x 4 column slices; wave (rw, sl) owns O[32 rows x its slice] -- the NSEG
+// segments of 128 columns are dealt 3/3/2/2-style to the slices -- so no wave holds more than 3 x 64 accumulator registers and
+// the finished fp32 scores of a row-wave are read once instead of once per 512-column slab.  Key tiles are 16 keys high (ONE
+// k-step of P.K; 32 keys x d bf16 would not leave room for a ring at d = 1280): 3 ring slots of NSEG x [16 keys][128 cols] with
+// the same swizzled image as the 32-key tiles.  P = 2^(x - reference) with the reference of the (row, chunk GROUP) = max of the
+// group's chunk maxima from the score pass: never above 1, no rescue path; the combine kernel weighs the groups.
+// Partials go out in the column-slab layout of the slab passes (the combine kernel reads both).
+template <int NSEG, int NRW>
+__global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
+                                                                       int tiles_per_chunk, int cg, int Bpad,
+                                                                       const float* __restrict__ xs,
+                                                                       const float* __restrict__ m_part,
+                                                                       uint4* __restrict__ o_part, long slab_stride) {
+    constexpr int NWAVES = 4 * NRW;
+    constexpr int NSW = (NSEG + 3) / 4;             // segments of the widest slice
+    constexpr int T16_BYTES = NSEG * 4096;          // 16 keys x d bf16
+    constexpr int NB = (163840 / T16_BYTES) > 6 ? 6 : (163840 / T16_BYTES);     // ring slots: all of the 160 KiB
+    constexpr int SD = NB - 1;                      // tiles requested ahead (keys by LDS-DMA, scores into registers)
+    constexpr int NPT = (NSEG * 4 + NWAVES - 1) / NWAVES;     // LDS-DMA pieces per wave and tile (1 KiB: 4 rows of a segment)
+    constexpr int OPT = NPT + 2;                    // vector-memory operations per wave and tile (2 score loads + the pieces)
+    static_assert(NB >= 3 && OPT * (SD - 1) <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rw = widx >> 2, sl = widx & 3;
+    const int n = lane & 31, h = lane >> 5;
+    const int ngroups = (nchunk + cg - 1) / cg;
+    const int nrb = Bpad / (32 * NRW);
+    // row blocks sharing a key group are 8 block ids apart when that tiles (same XCD, one L2 fetch of the keys)
+    int rb, grp;
+    {
+        const int id = blockIdx.x;
+        if ((ngroups & 7) == 0) {
+            const int g = id / (8 * nrb), r = id % (8 * nrb);
+            rb = r >> 3;
+            grp = g * 8 + (r & 7);
+        } else {
+            rb = id % nrb;
+            grp = id / nrb;
+        }
+    }
+    const int wb = rb * NRW + rw;                    // 32-row wave block of this wave
+    const int ntiles = (K + KT - 1) / KT;
+    const int c0 = grp * cg, c1 = min(c0 + cg, nchunk);
+    const int u0 = 2 * c0 * tiles_per_chunk;                              // 16-key tiles [u0, u1)
+    const int u1 = min(2 * min(c1 * tiles_per_chunk, ntiles), (K + 15) / 16);
+    // column slice of this wave: segments [sb, sb + nsw)
+    const int base = NSEG / 4, rem = NSEG % 4;
+    const int nsw = base + (sl < rem ? 1 : 0);
+    const int sb = sl * base + min(sl, rem);
+    const unsigned pitch = NSEG * 256;
+
+    float mref = NEG_BIG;
+    for (int c = c0; c < c1; ++c) mref = fmaxf(mref, m_part[(long)c * Bpad + wb * 32 + n]);
+
+    // ---- finished scores of 16-key tile u (half of a 32-key score tile in register order): 2 x 16 B per lane by inline asm
+    //      into a register ring, SD tiles ahead like the keys, counted by hand (LDS-DMA and ordinary loads share vmcnt; at
+    //      the first use of an ordinary load hipcc would drain the whole ring)
+    f32x4 sa[SD], sb4[SD];
+    const unsigned xlane = lane * 64;                                    // 16 floats per lane and 32-key tile, register order
+    auto load_scores = [&](int u, f32x4& d0, f32x4& d1) __attribute__((always_inline)) {
+        const char* xb = reinterpret_cast<const char*>(xs) + (((long)wb * ntiles + (u >> 1)) * 4096 + 32 * (u & 1));   // wave-uniform
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                     : "=&v"(d0), "=&v"(d1) : "v"(xlane), "s"(xb) : "memory");
+    };
+    // ---- LDS-DMA: piece pc of a tile = (segment pc>>2, row group pc&3); source lane term for row group rg = term0 ^ (rg << 4)
+    const int rl = lane >> 4, s16 = lane & 15;
+    const unsigned term0 = (unsigned)(rl * pitch + ((s16 ^ (rl << 2)) << 4));
+    // The LDS-DMA of this kernel is inline asm (scalar base + one lane offset + immediates; M0 written in the statement that
+    // reads it; no LDS-DMA builtin anywhere in the kernel, so hipcc has no M0 of its own to keep): the builtin cost ~12
+    // instructions per piece, and two waves per SIMD share the issue slots.  Wait states by hand: an SGPR written by the SALU
+    // code in front of the statement needs 5 states before a vector-memory instruction reads it as base (s_add + s_nop 3),
+    // M0 one state before the LDS-DMA.
+    // With 8 waves piece i of wave (rw, sl) is (segment 2i + rw, row group sl): ONE lane term per wave.
+    constexpr bool EVEN = (NSEG * 4) % NWAVES == 0 && NWAVES == 8;
+    const unsigned voff = term0 ^ (unsigned)(sl << 4);
+    auto dma_tile16 = [&](int u, unsigned lds_slot) __attribute__((always_inline)) {       // lds_slot: LDS byte address of the slot
+        const long key0 = (long)u * 16;
+        if (EVEN && key0 + 16 <= K) {
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (rw * 256 + sl * 4 * (int)pitch);
+            const unsigned dst = lds_slot + rw * 4096 + sl * 1024;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2"
+                             :: "v"(voff), "s"(src), "n"(i * 512), "s"(dst), "n"(i * 8192 - i * 512) : "memory", "scc");   // (the immediate offset moves the LDS destination too)
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            int pc = i * NWAVES + widx;
+            if (NSEG * 4 % NWAVES != 0) pc = pc < NSEG * 4 ? pc : 0;     // (padding pieces reload piece 0: equal counts per wave)
+            const int sg = pc >> 2, rg = pc & 3;
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + sg * 256;
+            unsigned off = term0 ^ (unsigned)(rg << 4);
+            if (key0 + 16 > K) {                    // the queue's last, partial tile: clamp rows past K (their P is 0)
+                const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
+                off = off - (unsigned)rl * pitch + (unsigned)row * pitch;
+            } else {
+                src += rg * 4 * (long)pitch;
+            }
+            const unsigned dst = lds_slot + sg * 4096 + rg * 1024;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(off), "s"(src), "s"(dst) : "memory");
+        }
+    };
+    // tiles are requested strictly in order, each as (2 score loads, NPT pieces): "tile v and everything older has landed"
+    // is s_waitcnt vmcnt(OPT x tiles requested after v)
+    auto wait_younger_tiles = [&](int j) __attribute__((always_inline)) {
+        switch (j) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPT) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT > 63 ? 63 : 2 * OPT) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPT > 63 ? 63 : 3 * OPT) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * OPT > 63 ? 63 : 4 * OPT) : "memory"); break;
+        }
+    };
+
+    // prologue: tiles u0 .. u0+SD-1 into slots 0 .. SD-1
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int j = 0; j < SD; ++j)
+        if (u0 + j < u1) {
+            load_scores(u0 + j, sa[j], sb4[j]);
+            dma_tile16(u0 + j, lds0 + j * T16_BYTES);
+        }
+
+    // O = 0 by MFMAs on zero operands with the inline-constant accumulator (see the one-pass kernel)
+    f32x16 O[NSW][4];
+    {
+        bf16x8 zq = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+        for (int s = 0; s < NSW; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                asm volatile("" : "+v"(zq));
+                O[s][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zq, zq, z, 0, 0, 0);
+            }
+    }
+    // transposed-read lane offsets (B operand: 16 keys x 32 columns), as in the one-pass kernel
+    int b_off;
+    {
+        const int i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
+        const int e = (2 * g2 + (p >> 1)) ^ h;
+        b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
+    }
+    wait_younger_tiles(max(min(u0 + SD - 1, u1 - 1) - u0, 0));           // tile u0 landed
+    __builtin_amdgcn_s_barrier();
+
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    int slot_cur = 0;                                                     // ring slot of tile u
+#pragma unroll 1
+    for (int ub = u0; ub < u1; ub += SD) {
+#pragma unroll
+        for (int j = 0; j < SD; ++j) {                                    // (unrolled: the score ring is indexed statically)
+            const int u = ub + j;
+            if (u < u1) {
+                asm volatile("" : "+v"(sa[j]), "+v"(sb4[j]));
+                float x[8] = {sa[j][0], sa[j][1], sa[j][2], sa[j][3], sb4[j][0], sb4[j][1], sb4[j][2], sb4[j][3]};
+                // tile u+SD: scores into the registers just read, keys into the slot of tile u-1 (free since the last barrier)
+                const int slot_free = slot_cur == 0 ? NB - 1 : slot_cur - 1;
+                if (u + SD < u1) {
+                    load_scores(u + SD, sa[j], sb4[j]);
+                    dma_tile16(u + SD, lds0 + slot_free * T16_BYTES);
+                }
+                if ((u + 1) * 16 > K) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (u * 16 + (i & 3) + 8 * (i >> 2) + 4 * h >= K) x[i] = NEG_BIG;
+                }
+                bf16x8 pa;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pa[i] = (__bf16)__builtin_amdgcn_exp2f(x[i] - mref);
+                const unsigned lb = lds0 + slot_cur * T16_BYTES + b_off + sb * 4096;
+#pragma unroll
+                for (int s = 0; s < NSW; ++s) {
+                    if (s < NSEG / 4 || s < nsw) {                           // (wave-uniform; only the last segment is conditional)
+                        s16x4 kb[4][2];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kb[c][0]) : "v"(lb ^ (c << 6)), "i"(s * 4096) : "memory");
+                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kb[c][1]) : "v"(lb ^ ((c << 6) | 32)), "i"(s * 4096 + 2048) : "memory");
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                            else if (c == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                            else if (c == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            asm volatile("" : "+v"(kb[c][0]), "+v"(kb[c][1]));
+                            const s16x8 k0 = __builtin_shufflevector(kb[c][0], kb[c][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                            O[s][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, k0), O[s][c], 0, 0, 0);
+                        }
+                    }
+                }
+                // tile u+1 (keys and scores) must have landed; the tiles requested after it may stay in flight
+                if (u + SD < u1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SD - 1) * OPT) : "memory");     // (steady state)
+                else wait_younger_tiles(max(u1 - 1 - (u + 1), 0));
+                __builtin_amdgcn_s_barrier();                                // ... and every wave is done with slot u
+                slot_cur = slot_cur == NB - 1 ? 0 : slot_cur + 1;
+            }
+        }
+    }
+
+    // ---- partial O of (group, wave block): slab layout of the slab passes (16 column tiles per 512-column slab)
+    if (wb * 32 < Bpad) {
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) {
+            if (s < nsw) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int C = (sb + s) * 4 + c;                         // column tile of the full row
+                    const int slab = C >> 4, cl = C & 15;
+                    const int nct = min(16, NSEG * 4 - 16 * slab);
+                    uint4* dst = o_part + slab * slab_stride + ((long)grp * (Bpad / 32) + wb) * (long)(nct * 2 * 64) + lane;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint4 v;
+                        v.x = (unsigned)f32_to_bf16(O[s][c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 1]) << 16);
+                        v.y = (unsigned)f32_to_bf16(O[s][c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 3]) << 16);
+                        v.z = (unsigned)f32_to_bf16(O[s][c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 5]) << 16);
+                        v.w = (unsigned)f32_to_bf16(O[s][c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 7]) << 16);
+                        dst[(cl * 2 + g) * 64] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // softmax statistics of the finished score scratch: wave = (row-wave rw, split of the key tiles); online max per lane,
 // halves merged at the end; writes (m, l, true max) in the partial format of the one-pass kernel (chunk = split)
 __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __restrict__ xs, int K, int ntiles, int Bpad,
-                                                                 int nsplit, float* __restrict__ m_part,
+                                                                 int nsplit, int per, float* __restrict__ m_part,
                                                                  float* __restrict__ l_part, float* __restrict__ x_part) {
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nrw = Bpad / 32;
     if (item >= nrw * nsplit) return;
     const int rw = item / nsplit, split = item - rw * nsplit;
-    const int per = (ntiles + nsplit - 1) / nsplit;
-    const int tb = split * per, te = min(tb + per, ntiles);
+    const int tb = split * per, te = min(tb + per, ntiles);       // per = tiles_per_chunk: split == key chunk of the slab passes
     float m = NEG_BIG, l = 0.f;
     for (int t = tb; t < te; ++t) {
         const float4* xa = reinterpret_cast<const float4*>(xs + (((long)rw * ntiles + t) * 64 + lane) * 16);
@@ -892,36 +1341,6 @@ __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __
     }
 }
 
-// dq[:, col0 : col0 + D] of one slab: sum of the chunks' normalised O partials plus the positive-key term
-//   dq = (sum_j p_j key_j + (p_0 - 1) k) / T ,  p_0 = exp(-loss_row)
-__global__ __launch_bounds__(256) void infonce_slab_dq_kernel(const unsigned* __restrict__ o_part, const float* __restrict__ k,
-                                                              const float* __restrict__ loss_rows, float* __restrict__ dq, int B,
-                                                              int dfull, int col0, int D, float inv_T, int nchunk, int Bpad) {
-    // block = one pair of rows (2m, 2m+1) = one packed word (g, h, w) of the partial layout, threads over the slab's columns
-    const int row0 = blockIdx.x * 2;
-    const int qq = row0 & 31, g = (qq >> 4) & 1, h = (qq >> 2) & 1, w = ((qq >> 3) & 1) * 2 + ((qq >> 1) & 1);
-    const int nct = D / 32;
-    const long wb_stride = (long)nct * 2 * 64 * 4, chunk_stride = (long)(Bpad / 32) * wb_stride;       // in 4-byte words
-    const unsigned* base = o_part + (long)(row0 >> 5) * wb_stride + (g * 64 + 32 * h) * 4 + w;
-    for (int col = threadIdx.x; col < D; col += blockDim.x) {
-        const unsigned* src = base + ((long)(col >> 5) * 2 * 64 + (col & 31)) * 4;
-        float a0 = 0.f, a1 = 0.f;
-        for (int c = 0; c < nchunk; ++c) {
-            const unsigned v = src[(long)c * chunk_stride];
-            a0 += __uint_as_float(v << 16);
-            a1 += __uint_as_float(v & 0xffff0000u);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int b = row0 + u;
-            if (b < B) {
-                const long o = (long)b * dfull + col0 + col;
-                dq[o] = ((u ? a1 : a0) + (expf(-loss_rows[b]) - 1.f) * k[o]) * inv_T;
-            }
-        }
-    }
-}
-
 // merge the key chunks of the 8 query rows of one (wave block, g, h) group -- they share the packed 16-B O words -- for one
 // group of 64 columns: add the positive logit (exact fp32), emit loss / lse / top-1 (column group 0 only) and dq.
 // Scalars: 32 threads per row.  dq: the 256 threads are 8 chunk-groups x 32 columns, one 16-B load (8 rows of a column) per
@@ -934,7 +1353,11 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                const float* __restrict__ l_part,
                                                                const float* __restrict__ x_part,
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
-                                                               int32_t* __restrict__ top1, float* __restrict__ dq) {
+                                                               int32_t* __restrict__ top1, float* __restrict__ dq,
+                                                               long slab_stride, int cg, int phase,
+                                                               float* __restrict__ rowstats) {
+    // phase 0: everything in one launch (every column-tile block repeats the row statistics: 16x at d = 512, cheap);
+    // wide rows (40 column tiles at d = 1280): phase 1 = statistics + loss / lse / top-1, weights to `rowstats`; phase 2 = dq
     __shared__ __attribute__((aligned(16))) float wts[COMBINE_MAX_CHUNKS][8];
     __shared__ float accs[8][8][32];
     __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
@@ -952,7 +1375,12 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
         return v;
     };
-    {
+    const int nparts = (nchunk + cg - 1) / cg;                            // partial buffers: one per chunk (group)
+    float* rs = rowstats + (long)blockIdx.x * (nparts * 8 + 16);
+    if (phase == 2) {
+        for (int i = tid; i < nparts * 8; i += 256) (&wts[0][0])[i] = rs[i];
+        if (tid < 16) (&rowc[0][0])[tid] = rs[nparts * 8 + tid];
+    } else {
         const int rr = tid >> 5, l32 = tid & 31;
         const int b = row_of(rr);
         const bool live = b < B;
@@ -975,8 +1403,16 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         float L = 0.f;
         for (int c = l32; c < nchunk; c += 32) {
             const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
-            wts[c][rr] = w;
+            if (cg == 1) wts[c][rr] = w;
             L += w * l_part[(long)c * Bpad + bb];
+        }
+        if (cg > 1) {
+            // O partials per GROUP of cg key chunks (wide P.K pass), relative to the largest reference of the group
+            for (int j = l32; j * cg < nchunk; j += 32) {
+                float mg = NEG_BIG;
+                for (int c = j * cg; c < min((j + 1) * cg, nchunk); ++c) mg = fmaxf(mg, m_part[(long)c * Bpad + bb]);
+                wts[j][rr] = exp2f(mg - M);
+            }
         }
         const float p0u = exp2f(s0l - M);
         L = sum32(L) + p0u;
@@ -991,16 +1427,24 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
             }
         }
     }
+    if (phase == 1) {
+        __syncthreads();
+        for (int i = tid; i < nparts * 8; i += 256) rs[i] = (&wts[0][0])[i];
+        if (tid < 16) rs[nparts * 8 + tid] = (&rowc[0][0])[tid];
+        return;
+    }
     if (dq == nullptr) return;
     __syncthreads();                                                     // wts[][], rowc[][] complete
     // dq: one 32-column tile of O per block; the 256 threads are 8 chunk-groups x 32 columns, every thread keeps up to 16 loads
     // of 16 B in flight (the kernel is one dependent sweep over 32 MB of partials: what matters is bytes in flight per CU)
-    const int col = tid & 31, cg = tid >> 5;
+    const int col = tid & 31, cgrp = tid >> 5;
+    // wide queues (D > 512) keep one partial buffer per column slab of 512 (the last one narrower), `slab_stride` uint4 apart
     const int c = blockIdx.y, n = col;
-    const int nct = D / 32;
+    const int sl = c >> 4, cl = c & 15;
+    const int nct = min(16, D / 32 - 16 * sl);
     const long wb_stride = (long)nct * 2 * 64;                           // uint4 per wave block
     const long chunk_stride = (long)(Bpad / 32) * wb_stride;
-    const uint4* src = o_part + (long)wb * wb_stride + (c * 2 + g) * 64 + h * 32 + n;
+    const uint4* src = o_part + sl * slab_stride + (long)wb * wb_stride + (cl * 2 + g) * 64 + h * 32 + n;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto fma8 = [&](const uint4& v, int ck) {
         const float4 w0 = *reinterpret_cast<const float4*>(&wts[ck][0]);
@@ -1014,20 +1458,27 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         acc[6] = fmaf(w1.z, __uint_as_float(v.w << 16), acc[6]);
         acc[7] = fmaf(w1.w, __uint_as_float(v.w & 0xffff0000u), acc[7]);
     };
-    int ck = cg;
-    for (; ck + 120 < nchunk; ck += 128) {                               // 16 loads in flight per lane
+    int ck = cgrp;
+    for (; ck + 120 < nparts; ck += 128) {                               // 16 loads in flight per lane
         uint4 v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) v[u] = src[(long)(ck + 8 * u) * chunk_stride];
 #pragma unroll
         for (int u = 0; u < 16; ++u) fma8(v[u], ck + 8 * u);
     }
-    for (; ck < nchunk; ck += 8) fma8(src[(long)ck * chunk_stride], ck);
+    for (; ck + 56 < nparts; ck += 64) {                                 // (fewer partial buffers: 8 loads in flight)
+        uint4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) accs[cg][i][col] = acc[i];
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(ck + 8 * u) * chunk_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fma8(v[u], ck + 8 * u);
+    }
+    for (; ck < nparts; ck += 8) fma8(src[(long)ck * chunk_stride], ck);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accs[cgrp][i][col] = acc[i];
     __syncthreads();
     {
-        const int i = cg;                                                // 8 rows x 32 columns of output, one per thread
+        const int i = cgrp;                                              // 8 rows x 32 columns of output, one per thread
         const int b = row_of(i);
         if (b < B) {
             float a = accs[0][i][col];
@@ -1061,6 +1512,7 @@ FlashPlan plan(int B, int K) {
 
 }  // namespace
 
+static int wide_pv_lds(int nseg) { const int nb = 163840 / (nseg * 4096); return (nb > 6 ? 6 : nb) * nseg * 4096; }
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
 static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
 
@@ -1074,8 +1526,10 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const FlashPlan p = plan(B, K);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     const int ds = d > 512 ? 512 : d;                        // widest slab
-    size_t bytes = rows * ds * 2 + 3 * rows * sizeof(float) + (size_t)p.Bpad * ds * 2 + 1024;
-    if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 256;     // score scratch
+    const int nslab = (d + 511) / 512;                       // one partial buffer per column slab
+    size_t bytes = (size_t)nslab * rows * ds * 2 + 3 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
+    if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 512       // score scratch
+                          + (size_t)(p.Bpad / 8) * (p.nchunk * 8 + 16) * sizeof(float);           // row statistics of the combine
     return bytes;
 }
 
@@ -1091,6 +1545,12 @@ void set_lds_attrs() {
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
     MOMA_SET_LDS(512); MOMA_SET_LDS(384); MOMA_SET_LDS(256); MOMA_SET_LDS(128);
 #undef MOMA_SET_LDS
+#define MOMA_SET_WIDE(NS, PS) (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<NS, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PS * 8192)
+    MOMA_SET_WIDE(5, 5); MOMA_SET_WIDE(6, 6); MOMA_SET_WIDE(8, 4); MOMA_SET_WIDE(10, 5); MOMA_SET_WIDE(12, 6);
+#undef MOMA_SET_WIDE
+#define MOMA_SET_WPV(NS) (void)hipFuncSetAttribute((const void*)infonce_wide_pv_kernel<NS, MOMA_K2_WIDE_NRW>, hipFuncAttributeMaxDynamicSharedMemorySize, wide_pv_lds(NS))
+    MOMA_SET_WPV(5); MOMA_SET_WPV(6); MOMA_SET_WPV(8); MOMA_SET_WPV(10); MOMA_SET_WPV(12);
+#undef MOMA_SET_WPV
 }
 }  // namespace
 
@@ -1111,41 +1571,81 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     const bf16_raw* qu = (const bf16_raw*)queue;
     const dim3 grid(p.nbt * p.nchunk), block(256);
     if (d > 512) {
-        // ---- wide queue: column slabs.  scores -> scratch (one launch per slab), statistics, lse / loss / top-1, then
-        //      per slab P.K and the slab's columns of dq
-        float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * dsl * 2) + 255) & ~(uintptr_t)255);
+        // ---- wide queue.  Scores of every (row, key) -> fp32 scratch + per-chunk (max, sum): ONE pass with the whole Q row block
+        //      in registers when d is 5 / 6 / 8 / 10 / 12 segments of 128 columns (d <= 1536), else one pass per column slab
+        //      (the slab adds its partial scores to the scratch) and a statistics pass.  Then, for dq, per column slab of <= 512:
+        //      O = sum 2^(x - chunk max) key over the chunk (P.K on the slab's columns), and ONE combine launch for loss / lse /
+        //      top-1 / dq over all slabs.
+        const int nslab = (d + 511) / 512;
+        const size_t slab_bytes = rows * 512 * 2;
+        qpack = (uint4*)(((uintptr_t)((char*)o_part + (size_t)nslab * slab_bytes) + 255) & ~(uintptr_t)255);
+        float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * d * 2) + 255) & ~(uintptr_t)255);
         const int ntiles = (K + KT - 1) / KT;
         auto slab_width = [&](int col0) { const int rem = d - col0; return rem >= 512 ? 512 : rem; };   // 512.., then 384/256/128
         if (ev_begin) (void)hipEventRecord(ev_begin, st);
-        for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
-            const int D = slab_width(col0);
-            const SlabArgs sa{xs, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
-            const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
-#define MOMA_SLAB_SCORES(DD)                                                                                             \
-            do {                                                                                                         \
-                hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2, qpack, p.Bpad / 32); \
-                hipLaunchKernelGGL((infonce_slab_kernel<DD, 1>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa); \
-            } while (0)
-            if (D == 512) MOMA_SLAB_SCORES(512); else if (D == 384) MOMA_SLAB_SCORES(384); else if (D == 256) MOMA_SLAB_SCORES(256); else MOMA_SLAB_SCORES(128);
-#undef MOMA_SLAB_SCORES
-        }
-        hipLaunchKernelGGL(infonce_slab_stats_kernel, dim3(((p.Bpad / 32) * p.nchunk + 3) / 4), dim3(256), 0, st, xs, K, ntiles,
-                           p.Bpad, p.nchunk, m_part, l_part, x_part);
-        hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
-                           m_part, l_part, x_part, loss_rows, lse, top1, (float*)nullptr);
-        if (dq) {
+        const int nseg = d / 128;
+#define MOMA_WIDE_SCORES(NS, PS, DD)                                                                                          \
+        do {                                                                                                                  \
+            hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
+            hipLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192, st, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, xs, m_part, l_part, x_part); \
+        } while (0)
+        if (nseg == 5) MOMA_WIDE_SCORES(5, 5, 640);
+        else if (nseg == 6) MOMA_WIDE_SCORES(6, 6, 768);
+        else if (nseg == 8) MOMA_WIDE_SCORES(8, 4, 1024);
+        else if (nseg == 10) MOMA_WIDE_SCORES(10, 5, 1280);
+        else if (nseg == 12) MOMA_WIDE_SCORES(12, 6, 1536);
+        else {
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
                 const int D = slab_width(col0);
-                const SlabArgs sa{xs, lse, (unsigned)(d * 2), 0};
+                const SlabArgs sa{xs, nullptr, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
                 const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
-#define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa)
-                if (D == 512) MOMA_SLAB_PV(512); else if (D == 384) MOMA_SLAB_PV(384); else if (D == 256) MOMA_SLAB_PV(256); else MOMA_SLAB_PV(128);
+#define MOMA_SLAB_SCORES(DD)                                                                                             \
+                do {                                                                                                         \
+                    hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2, qpack, p.Bpad / 32); \
+                    hipLaunchKernelGGL((infonce_slab_kernel<DD, 1>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, sa); \
+                } while (0)
+                if (D == 512) MOMA_SLAB_SCORES(512); else if (D == 384) MOMA_SLAB_SCORES(384); else if (D == 256) MOMA_SLAB_SCORES(256); else MOMA_SLAB_SCORES(128);
+#undef MOMA_SLAB_SCORES
+            }
+            hipLaunchKernelGGL(infonce_slab_stats_kernel, dim3(((p.Bpad / 32) * p.nchunk + 3) / 4), dim3(256), 0, st, xs, K, ntiles,
+                               p.Bpad, p.nchunk, p.tiles_per_chunk, m_part, l_part, x_part);
+        }
+#undef MOMA_WIDE_SCORES
+        int cg = 1;
+        if (dq) {
+            const bool wide_pv = nseg == 5 || nseg == 6 || nseg == 8 || nseg == 10 || nseg == 12;
+            if (wide_pv) {
+                // one pass over all columns; key chunks grouped so that the grid is about one workgroup per CU
+                constexpr int NRW = MOMA_K2_WIDE_NRW;
+                const int nrb = p.Bpad / (32 * NRW);
+                int want = 256 / nrb;
+                if (want < 1) want = 1;
+                cg = (p.nchunk + want - 1) / want;
+                const int ngroups = (p.nchunk + cg - 1) / cg;
+#define MOMA_WIDE_PV(NS) hipLaunchKernelGGL((infonce_wide_pv_kernel<NS, NRW>), dim3(nrb * ngroups), dim3(256 * NRW), wide_pv_lds(NS), st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16))
+                if (nseg == 5) MOMA_WIDE_PV(5); else if (nseg == 6) MOMA_WIDE_PV(6); else if (nseg == 8) MOMA_WIDE_PV(8);
+                else if (nseg == 10) MOMA_WIDE_PV(10); else MOMA_WIDE_PV(12);
+#undef MOMA_WIDE_PV
+            } else {
+                int sl = 0;
+                for (int col0 = 0; col0 < d; col0 += slab_width(col0), ++sl) {
+                    const int D = slab_width(col0);
+                    const SlabArgs sa{xs, nullptr, m_part, (unsigned)(d * 2), 0};
+                    const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
+                    uint4* op = (uint4*)((char*)o_part + (size_t)sl * slab_bytes);
+#define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, op, sa)
+                    if (D == 512) MOMA_SLAB_PV(512); else if (D == 384) MOMA_SLAB_PV(384); else if (D == 256) MOMA_SLAB_PV(256); else MOMA_SLAB_PV(128);
 #undef MOMA_SLAB_PV
-                hipLaunchKernelGGL(infonce_slab_dq_kernel, dim3((B + 1) / 2), dim3(256), 0, st, (const unsigned*)o_part, k, loss_rows, dq,
-                                   B, d, col0, D, inv_T, p.nchunk, p.Bpad);
+                }
             }
         }
-        if (ev_end) (void)hipEventRecord(ev_end, st);          // (the measurement hook spans every pass of the slab path)
+        float* rowstats = (float*)(((uintptr_t)((char*)xs + (size_t)p.Bpad * ntiles * KT * sizeof(float)) + 255) & ~(uintptr_t)255);
+        hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
+                           m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, dq ? 1 : 0, rowstats);
+        if (dq)
+            hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, d / 32), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
+                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, 2, rowstats);
+        if (ev_end) (void)hipEventRecord(ev_end, st);          // (the measurement hook spans every pass of the wide path)
         return hipGetLastError();
     }
     const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
@@ -1167,7 +1667,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
-                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq);
+                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 0, (float*)nullptr);
     return hipGetLastError();
 }
 
