@@ -1,17 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-L=gpurun_out/r2_k1a.log
-timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "mha or gemm or linear or attention or moco" > gpurun_out/r2_tk1a.log 2>&1; echo "pytest rc=$?" > $L
-tail -8 gpurun_out/r2_tk1a.log >> $L
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_k1a
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_k1a -o w --output-format csv -- python3 $R/scripts/bench_k1.py 256 512 4 > $R/gpurun_out/prof_k1a.log 2>&1
-cd $R
-python - >> $L <<'PY'
-import csv,glob
-f=glob.glob('gpurun_out/prof_k1a/**/*kernel_stats.csv',recursive=True)[0]
-for r in csv.DictReader(open(f)):
-    if 'moma' in r['Name']: print(r['Name'][:90], r['Calls'], r['AverageNs'], r['MinNs'])
-PY
-grep -v amdgpu.ids $L
+bash scripts/collect_profiles.sh r02 > gpurun_out/collect_r02.log 2>&1
+tail -30 gpurun_out/collect_r02.log
+python bench.py > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -1 gpurun_out/bench_r02.json
+python bench.py --head None --no_cpu_baseline > gpurun_out/bench_r02_head_none.json 2> gpurun_out/bench_r02_head_none.err; tail -1 gpurun_out/bench_r02_head_none.json
