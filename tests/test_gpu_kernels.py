@@ -751,8 +751,12 @@ def test_effnet_weight_cache_is_transparent():
     # MIOpen's bf16 weight gradients use split reductions with atomics and bf16 partial sums: two runs of the SAME code differ
     # by a few bf16 ulps of the largest partial (observed run-to-run spread up to 3.2e-2 of max|g| on the stem convolution), so
     # the bound is that spread -- what the cache could break (stale or wrong copies) shows as O(1) differences
+    # Gradients that are mathematically ZERO (the bias of a BatchNorm whose output reaches the loss only through convolution ->
+    # train-mode BatchNorm: `_blocks.*._bn2.bias`, max|g| ~1e-4 against ~1e-1 elsewhere) are pure rounding noise, different on
+    # every run (scripts/diag_wcache.py): each tensor is measured against max(its own scale, 1 % of the largest gradient).
+    gmax = max(g.abs().max().item() for g in g0.values())
     for n in g0:
-        err = (g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), 1e-12)
+        err = (g1[n] - g0[n]).abs().max().item() / max(g0[n].abs().max().item(), 1e-2 * gmax)
         assert err < 6e-2, (n, err)
     with torch.no_grad():
         net._conv_stem.weight.mul_(2.0)                        # an optimizer step / EMA update changes the masters ...
