@@ -27,4 +27,5 @@ for i, (y, g) in enumerate(runs[1:], 1):
         if e > worst.get(n, (0, 0))[0]: worst[n] = (e, i)
 top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:12]
 for n, (e, i) in top: print(f"{n:40s} spread {e:.3e} (run {i})  max|g| {ref[n].abs().max().item():.3e}")
+print("largest gradient", max(g.abs().max().item() for g in ref.values()))
 print("logit spread", max((r[0].float() - runs[0][0].float()).abs().max().item() for r in runs[1:]), "max|y|", runs[0][0].float().abs().max().item())
