@@ -141,7 +141,11 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
                                        (129, 512, 65536, "bf16"), (200, 128, 16384, "bf16"), (9, 128, 65, "bf16"),
                                        # d > 512: column slabs over a score scratch (512 + 512 + 256, 512 + 128, 4 x 512, 512 + 384)
                                        (64, 1280, 4096, "bf16"), (33, 640, 1000, "bf16"), (40, 2048, 777, "bf16"),
-                                       (130, 896, 2100, "bf16")])
+                                       (130, 896, 2100, "bf16"),
+                                       # the one-pass wide kernels at their other widths (8 / 12 / 6 segments), ragged B and K,
+                                       # several key chunks per group and a last 16-key tile that is partly past K
+                                       (70, 1024, 3000, "bf16"), (257, 1536, 2500, "bf16"), (96, 768, 70001, "bf16"),
+                                       (5, 1280, 17, "bf16")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
@@ -173,7 +177,7 @@ def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
 
 
 @pytest.mark.parametrize("B,d,K", [(256, 512, 4096), (100, 384, 1000), (33, 256, 300), (128, 512, 65536), (70, 128, 2000), (50, 1280, 1500),
-                                   (160, 768, 3000)])
+                                   (160, 768, 3000), (256, 1280, 65536), (90, 1024, 20000)])
 def test_infonce_flash_queue_term(ops, B, d, K):
     """The sum_j p_bj * queue_j part of dq in isolation: k = 0 removes the positive-key term, and every query is
     aligned with a few queue rows so the softmax is peaked and the weighted key sum is O(1), not averaged away."""
@@ -197,6 +201,36 @@ def test_infonce_flash_queue_term(ops, B, d, K):
     assert rown.min() > 0.5                       # the term under test is not negligible
     err = np.linalg.norm(got - ref_dq, axis=1) / rown
     assert err.max() < 2e-2, err.max()
+
+
+@pytest.mark.parametrize("d", [768, 1280])
+def test_infonce_wide_rows_large_logits_and_repeatable(ops, d):
+    """Wide rows (d > 512): P = 2^(x - reference) with the reference = max over the chunk group of the chunk maxima of the score
+    pass, so logits tens of nats apart (un-normalised attention outputs as q, reference MoMA/criterion_moco_att.py:153-167)
+    need no rescue path; and the path has no atomics: two calls give the same bits."""
+    rng = np.random.default_rng(d)
+    B, K, T = 96, 9000, 0.15
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    hot = rng.integers(0, K, size=B)
+    q = (queue[hot] * rng.uniform(2.0, 14.0, size=(B, 1)) + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (0.5 * q).astype(np.float32)
+    tqueue = _t(queue, torch.bfloat16)
+    qe = tqueue.float().cpu().numpy()
+    ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, qe, T) * B
+    outs = []
+    for _ in range(2):
+        tq = _t(q).requires_grad_(True)
+        loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), tqueue, T, "bf16")
+        loss_rows.sum().backward()
+        outs.append((loss_rows.detach().clone(), lse.clone(), tq.grad.clone()))
+    assert np.ptp(ref["lse"]) > 20.0                                     # the rows really are tens of nats apart
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref["lse"], rtol=2e-3, atol=5e-2)
+    got = outs[0][2].cpu().numpy()
+    err = np.linalg.norm(got - ref_dq, axis=1) / np.maximum(np.linalg.norm(ref_dq, axis=1), 1e-3)
+    assert err.max() < 3e-2, err.max()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("grad", [True, False])
