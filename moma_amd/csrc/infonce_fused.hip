@@ -29,6 +29,7 @@
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
 // which is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
 #include "common.hpp"
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -58,10 +59,6 @@ extern "C" int moma_debug_read_stamps(unsigned* host) {
 #else
 #define K2_STAMP_BYTES 0
 #define K2_STAMP(neg, pos) do { } while (0)
-#endif
-
-#ifndef MOMA_K2_WIDE_NRW
-#define MOMA_K2_WIDE_NRW 2      // row-waves per workgroup of the wide P.K pass (2: a key tile serves 64 query rows)
 #endif
 
 namespace moma {
@@ -1070,47 +1067,58 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
 // the same swizzled image as the 32-key tiles.  P = 2^(x - reference) with the reference of the (row, chunk GROUP) = max of the
 // group's chunk maxima from the score pass: never above 1, no rescue path; the combine kernel weighs the groups.
 // Partials go out in the column-slab layout of the slab passes (the combine kernel reads both).
-template <int NSEG, int NRW>
-__global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
-                                                                       int tiles_per_chunk, int cg, int Bpad,
-                                                                       const float* __restrict__ xs,
-                                                                       const float* __restrict__ m_part,
-                                                                       uint4* __restrict__ o_part, long slab_stride) {
-    constexpr int NWAVES = 4 * NRW;
-    constexpr int NSW = (NSEG + 3) / 4;             // segments of the widest slice
-    constexpr int T16_BYTES = NSEG * 4096;          // 16 keys x d bf16
-    constexpr int NB = (163840 / T16_BYTES) > 6 ? 6 : (163840 / T16_BYTES);     // ring slots: all of the 160 KiB
+template <int NSEG, int CSEG>
+__global__ __launch_bounds__(512, 1) void infonce_wide_pv_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
+                                                                 int tiles_per_chunk, int cg, int Bpad,
+                                                                 const float* __restrict__ xs,
+                                                                 const float* __restrict__ m_part,
+                                                                 uint4* __restrict__ o_part, long slab_stride) {
+    // CSEG = segments of the workgroup's COLUMN RANGE.  CSEG == NSEG: all columns, 2 row-waves x 4 slices (the keys cross
+    // L2 -> CU once per 64 query rows, the scores once).  CSEG == 2: one 256-column range per workgroup, 8 row-waves x 1 slice
+    // (the keys cross once per 256 rows, the scores once per column range) -- less traffic in all when d/256 < rows/64.
+    constexpr int NWAVES = 8;
+    constexpr int NSL = CSEG == NSEG ? 4 : 1;       // column slices inside the workgroup
+    constexpr int NRW = NWAVES / NSL;               // row-waves (32 query rows each) of the workgroup
+    constexpr int NCR = (NSEG + CSEG - 1) / CSEG;   // column ranges of the row
+    constexpr int NSW = (CSEG + NSL - 1) / NSL;     // segments of the widest slice
+    constexpr int T16_BYTES = CSEG * 4096;          // 16 keys x the range's columns, bf16
+    constexpr int NB = (163840 / T16_BYTES) > 6 ? 6 : (163840 / T16_BYTES);     // ring slots (d = 1280, all columns: the 160 KiB)
     constexpr int SD = NB - 1;                      // tiles requested ahead (keys by LDS-DMA, scores into registers)
-    constexpr int NPT = (NSEG * 4 + NWAVES - 1) / NWAVES;     // LDS-DMA pieces per wave and tile (1 KiB: 4 rows of a segment)
+    constexpr int NPT = (CSEG * 4 + NWAVES - 1) / NWAVES;     // LDS-DMA pieces per wave and tile (1 KiB: 4 rows of a segment)
     constexpr int OPT = NPT + 2;                    // vector-memory operations per wave and tile (2 score loads + the pieces)
     static_assert(NB >= 3 && OPT * (SD - 1) <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rw = widx >> 2, sl = widx & 3;
+    const int rw = widx / NSL, sl = widx % NSL;
+    const int wq = widx >> 2, wr = widx & 3;          // LDS-DMA role of the wave: piece i = (segment 2i + wq, row group wr)
     const int n = lane & 31, h = lane >> 5;
     const int ngroups = (nchunk + cg - 1) / cg;
-    const int nrb = Bpad / (32 * NRW);
-    // row blocks sharing a key group are 8 block ids apart when that tiles (same XCD, one L2 fetch of the keys)
-    int rb, grp;
+    const int nrb = (Bpad / 32 + NRW - 1) / NRW;
+    const int nj = nrb * NCR;                         // workgroups per key group: (row block, column range)
+    // the workgroups of one key group are 8 block ids apart when that tiles (same XCD: one L2 fetch of the keys and scores)
+    int jj, grp;
     {
         const int id = blockIdx.x;
         if ((ngroups & 7) == 0) {
-            const int g = id / (8 * nrb), r = id % (8 * nrb);
-            rb = r >> 3;
+            const int g = id / (8 * nj), r = id % (8 * nj);
+            jj = r >> 3;
             grp = g * 8 + (r & 7);
         } else {
-            rb = id % nrb;
-            grp = id / nrb;
+            jj = id % nj;
+            grp = id / nj;
         }
     }
-    const int wb = rb * NRW + rw;                    // 32-row wave block of this wave
+    const int rb = jj / NCR, cr = jj % NCR;
+    const int wb = min(rb * NRW + rw, Bpad / 32 - 1);  // 32-row wave block of this wave (a wave past the rows repeats the last one)
+    const bool live = rb * NRW + rw < Bpad / 32;
     const int ntiles = (K + KT - 1) / KT;
     const int c0 = grp * cg, c1 = min(c0 + cg, nchunk);
     const int u0 = 2 * c0 * tiles_per_chunk;                              // 16-key tiles [u0, u1)
     const int u1 = min(2 * min(c1 * tiles_per_chunk, ntiles), (K + 15) / 16);
-    // column slice of this wave: segments [sb, sb + nsw)
-    const int base = NSEG / 4, rem = NSEG % 4;
+    // column range of the workgroup: segments [cb, cb + ncs); slice of this wave inside it: segments [sb, sb + nsw) of the range
+    const int cb = cr * CSEG, ncs = min(CSEG, NSEG - cb);
+    const int base = ncs / NSL, rem = ncs % NSL;
     const int nsw = base + (sl < rem ? 1 : 0);
     const int sb = sl * base + min(sl, rem);
     const unsigned pitch = NSEG * 256;
@@ -1137,13 +1145,13 @@ __global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf1
     // code in front of the statement needs 5 states before a vector-memory instruction reads it as base (s_add + s_nop 3),
     // M0 one state before the LDS-DMA.
     // With 8 waves piece i of wave (rw, sl) is (segment 2i + rw, row group sl): ONE lane term per wave.
-    constexpr bool EVEN = (NSEG * 4) % NWAVES == 0 && NWAVES == 8;
-    const unsigned voff = term0 ^ (unsigned)(sl << 4);
+    constexpr bool EVEN = (CSEG * 4) % NWAVES == 0;
+    const unsigned voff = term0 ^ (unsigned)(wr << 4);
     auto dma_tile16 = [&](int u, unsigned lds_slot) __attribute__((always_inline)) {       // lds_slot: LDS byte address of the slot
         const long key0 = (long)u * 16;
-        if (EVEN && key0 + 16 <= K) {
-            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (rw * 256 + sl * 4 * (int)pitch);
-            const unsigned dst = lds_slot + rw * 4096 + sl * 1024;
+        if (EVEN && ncs == CSEG && key0 + 16 <= K) {
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + ((cb + wq) * 256 + wr * 4 * (int)pitch);
+            const unsigned dst = lds_slot + wq * 4096 + wr * 1024;
 #pragma unroll
             for (int i = 0; i < NPT; ++i)
                 asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2"
@@ -1153,9 +1161,9 @@ __global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf1
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             int pc = i * NWAVES + widx;
-            if (NSEG * 4 % NWAVES != 0) pc = pc < NSEG * 4 ? pc : 0;     // (padding pieces reload piece 0: equal counts per wave)
+            pc = pc < ncs * 4 ? pc : 0;                                   // (padding pieces reload piece 0: equal counts per wave)
             const int sg = pc >> 2, rg = pc & 3;
-            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + sg * 256;
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (cb + sg) * 256;
             unsigned off = term0 ^ (unsigned)(rg << 4);
             if (key0 + 16 > K) {                    // the queue's last, partial tile: clamp rows past K (their P is 0)
                 const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
@@ -1241,7 +1249,7 @@ __global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf1
                 const unsigned lb = lds0 + slot_cur * T16_BYTES + b_off + sb * 4096;
 #pragma unroll
                 for (int s = 0; s < NSW; ++s) {
-                    if (s < NSEG / 4 || s < nsw) {                           // (wave-uniform; only the last segment is conditional)
+                    if (s < nsw) {                                           // (wave-uniform)
                         s16x4 kb[4][2];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -1270,13 +1278,255 @@ __global__ __launch_bounds__(256 * NRW, 1) void infonce_wide_pv_kernel(const bf1
     }
 
     // ---- partial O of (group, wave block): slab layout of the slab passes (16 column tiles per 512-column slab)
-    if (wb * 32 < Bpad) {
+    if (live) {
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
             if (s < nsw) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int C = (sb + s) * 4 + c;                         // column tile of the full row
+                    const int C = (cb + sb + s) * 4 + c;                    // column tile of the full row
+                    const int slab = C >> 4, cl = C & 15;
+                    const int nct = min(16, NSEG * 4 - 16 * slab);
+                    uint4* dst = o_part + slab * slab_stride + ((long)grp * (Bpad / 32) + wb) * (long)(nct * 2 * 64) + lane;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint4 v;
+                        v.x = (unsigned)f32_to_bf16(O[s][c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 1]) << 16);
+                        v.y = (unsigned)f32_to_bf16(O[s][c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 3]) << 16);
+                        v.z = (unsigned)f32_to_bf16(O[s][c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 5]) << 16);
+                        v.w = (unsigned)f32_to_bf16(O[s][c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 7]) << 16);
+                        dst[(cl * 2 + g) * 64] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- wide queues, P.K by COLUMN RANGES ---------------------------------------------------------------------------------------
+// Workgroup = 8 row-waves (256 query rows) x ONE range of 256 columns (2 segments): the keys of the range cross L2 -> CU once per
+// 256 rows, the scores once per range; wave w owns O[32 rows x 256 columns] = 128 accumulator registers (two waves per SIMD).
+// 32-key tiles in the standard swizzled image (2 segments x 8 KiB per ring slot, 6 slots), so one workgroup barrier serves 16
+// MFMAs per wave; keys (2 LDS-DMA pieces per wave) and scores (4 x 16 B per lane, register ring) are requested SD tiles ahead by
+// inline asm and counted by hand.  P of tile t+1 is formed BEFORE the barrier that ends tile t (the scores are in registers), in
+// the shadow of tile t's last MFMAs; the transposed reads run two column tiles ahead of their MFMAs (hand-counted lgkmcnt).
+// Reference of P and partial layout as in the kernel above.
+template <int NSEG>
+__global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
+                                                                  int tiles_per_chunk, int cg, int Bpad,
+                                                                  const float* __restrict__ xs, const float* __restrict__ m_part,
+                                                                  uint4* __restrict__ o_part, long slab_stride) {
+    constexpr int NCR = (NSEG + 1) / 2;             // column ranges of the row
+    constexpr int SLOT = 2 * 8192;                  // 32 keys x 256 columns bf16
+    constexpr int NB = 4, SD = 3;                   // ring slots; tiles requested ahead (scores: 16 registers per tile)
+    constexpr int OPT = 6;                          // vector-memory operations per wave and tile: 4 score loads + 2 pieces
+    constexpr int PF = 2;                           // column tiles of transposed reads in flight
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const int ngroups = (nchunk + cg - 1) / cg;
+    const int nrb = (Bpad / 32 + 7) / 8;
+    const int nj = nrb * NCR;
+    // block id -> (key group, member): blocks go round-robin to the 8 XCDs, so XCD x = id % 8 takes the groups g = 8i + x and all
+    // nj members (row block, column range) of a group sit on ONE XCD -- the scores are fetched into its L2 once, not once per
+    // range (measured without it: FETCH_SIZE 492 MB instead of 235).  The grid is padded to 8 * ceil(ngroups / 8) * nj blocks.
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int grp = (kk / nj) * 8 + xcd, jj = kk % nj;
+    if (grp >= ngroups) return;
+    const int rb = jj / NCR, cr = jj % NCR;
+    const bool live = rb * 8 + w < Bpad / 32;
+    const int wb = min(rb * 8 + w, Bpad / 32 - 1);  // (a wave past the rows repeats the last block and stores nothing)
+    const int ntiles = (K + KT - 1) / KT;
+    const int c0 = grp * cg, c1 = min(c0 + cg, nchunk);
+    const int t0 = c0 * tiles_per_chunk, t1 = min(c1 * tiles_per_chunk, ntiles);
+    const int cb = cr * 2, ncs = min(2, NSEG - cb);
+    const unsigned pitch = NSEG * 256;
+
+    float mref = NEG_BIG;
+    for (int c = c0; c < c1; ++c) mref = fmaxf(mref, m_part[(long)c * Bpad + wb * 32 + n]);
+
+    // ---- scores of tile t: 16 floats per lane in register order
+    f32x4 sx[SD][4];
+    const unsigned xlane = lane * 64;
+    auto load_scores = [&](int t, f32x4 (&d)[4]) __attribute__((always_inline)) {
+        const char* xb = reinterpret_cast<const char*>(xs) + ((long)wb * ntiles + t) * 4096;          // wave-uniform
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:32\n\tglobal_load_dwordx4 %3, %4, %5 offset:48"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(xlane), "s"(xb) : "memory");
+    };
+    // ---- keys of tile t: wave w issues row group w (4 rows) of both segments (of segment 0 twice when the range has one)
+    const int rl = lane >> 4, s16 = lane & 15;
+    const unsigned term0 = (unsigned)(rl * pitch + ((s16 ^ (rl << 2)) << 4));
+    const unsigned voff = term0 ^ (unsigned)((w & 3) << 4);
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+    auto dma_tile = [&](int t, unsigned lds_slot) __attribute__((always_inline)) {
+        const long key0 = (long)t * KT;
+        const unsigned dst = lds_slot + w * 1024;
+        const int seg1 = ncs == 2 ? 256 : 0;        // (one-segment range: the second piece repeats the first into the unused half)
+        if (key0 + KT <= K) {
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (cb * 256 + w * 4 * (int)pitch);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff), "s"(src + seg1), "s"(dst + 8192) : "memory");
+        } else {                                    // the queue's last, partial tile: clamp rows past K (their P is 0)
+            const int row = min(w * 4 + rl, (int)(K - 1 - key0));
+            const unsigned off = voff - (unsigned)rl * pitch + (unsigned)row * pitch;
+            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + cb * 256;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(off), "s"(src + seg1), "s"(dst + 8192) : "memory");
+        }
+    };
+    auto wait_younger_tiles = [&](int j) __attribute__((always_inline)) {          // tiles requested after the one awaited
+        switch (j) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPT) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT) : "memory"); break;
+        }
+    };
+    static_assert(SD == 3, "wait_younger_tiles covers SD - 1 = 2 younger tiles");
+#pragma unroll
+    for (int j = 0; j < SD; ++j)
+        if (t0 + j < t1) {
+            load_scores(t0 + j, sx[j]);
+            dma_tile(t0 + j, lds0 + j * SLOT);
+        }
+
+    f32x16 O[2][4];
+    {
+        bf16x8 zq = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                asm volatile("" : "+v"(zq));
+                O[s][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zq, zq, z, 0, 0, 0);
+            }
+    }
+    int b_off;
+    {
+        const int i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
+        const int e = (2 * g2 + (p >> 1)) ^ h;
+        b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
+    }
+    // P of a tile from its scores: register r = key (r&3) + 8*(r>>2) + 4h of the tile; registers 8s..8s+7 = A fragment of k-step s
+    auto make_p = [&](const f32x4 (&d)[4], int t, bf16x8 (&pa)[2]) __attribute__((always_inline)) {
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = d[r >> 2][r & 3];
+        if ((t + 1) * KT > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pa[s][i] = (__bf16)__builtin_amdgcn_exp2f(x[8 * s + i] - mref);
+    };
+    bf16x8 pa[2];
+    wait_younger_tiles(max(min(t0 + SD - 1, t1 - 1) - t0, 0));           // tile t0 landed
+    asm volatile("" : "+v"(sx[0][0]), "+v"(sx[0][1]), "+v"(sx[0][2]), "+v"(sx[0][3]));
+    make_p(sx[0], t0, pa);
+    __builtin_amdgcn_s_barrier();
+
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    int slot_cur = 0;
+#pragma unroll 1
+    for (int tb = t0; tb < t1; tb += SD) {
+#pragma unroll
+        for (int j = 0; j < SD; ++j) {                                    // (unrolled: the score ring is indexed statically)
+            const int t = tb + j;
+            if (t < t1) {
+                // tile t+SD: scores into the registers consumed last iteration, keys into the slot freed by the last barrier
+                {
+                    const int slot_free = slot_cur >= NB - SD ? slot_cur - (NB - SD) : slot_cur + SD;
+                    if (t + SD < t1) {
+                        load_scores(t + SD, sx[j]);
+                        dma_tile(t + SD, lds0 + slot_free * SLOT);
+                    }
+                }
+                // O += P(t) . K_tile: column tile ct = 4*seg + c; its 4 transposed reads run PF column tiles ahead
+                const unsigned lb = lds0 + slot_cur * SLOT + b_off;
+                s16x4 kb[PF + 1][4];
+                auto issue = [&](int ct) __attribute__((always_inline)) {
+                    const int sgi = ct >> 2, c = ct & 3;
+                    s16x4* k4 = kb[ct % (PF + 1)];
+                    const unsigned a0 = lb ^ (unsigned)(c << 6), a1 = a0 ^ 32u;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(a0), "i"(0) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(a1), "i"(2048) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(a0), "i"(4096) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(a1), "i"(6144) : "memory");
+                    (void)sgi;
+                };
+                const int nct = 4 * ncs;                                  // 4 or 8 column tiles (wave-uniform)
+                // (the second segment's reads take their 8 KiB from the immediate offset: separate statements per segment)
+                auto issue_seg = [&](int ct) __attribute__((always_inline)) {
+                    if ((ct >> 2) == 0) issue(ct);
+                    else {
+                        const int c = ct & 3;
+                        s16x4* k4 = kb[ct % (PF + 1)];
+                        const unsigned a0 = lb ^ (unsigned)(c << 6), a1 = a0 ^ 32u;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(a0), "i"(8192) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(a1), "i"(8192 + 2048) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(a0), "i"(8192 + 4096) : "memory");
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(a1), "i"(8192 + 6144) : "memory");
+                    }
+                };
+#pragma unroll
+                for (int ct = 0; ct < PF; ++ct) issue_seg(ct);
+                // tile t+1 (keys and scores, requested two iterations ago) has landed by now; the tiles requested after it stay
+                // in flight.  P(t+1) is formed in the shadow of this tile's MFMAs, 4 (or 2) scores per column tile.
+                wait_younger_tiles(max(min(t + SD, t1 - 1) - (t + 1), 0));
+                f32x4 (&nx)[4] = sx[(j + 1) % SD];
+                asm volatile("" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]));
+                bf16x8 pn[2];
+                const bool tail = (t + 2) * KT > K;                       // tile t+1 reaches past K: its late keys get P = 0
+                auto p_step = [&](int r) __attribute__((always_inline)) {  // score register r of tile t+1
+                    float x = nx[r >> 2][r & 3];
+                    if (tail && (t + 1) * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x = NEG_BIG;
+                    pn[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(x - mref);
+                };
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    if (ct < nct) {
+                        if (ct + PF < nct) issue_seg(ct + PF);
+                        // in flight behind column tile ct: min(PF, nct - 1 - ct) tiles of 4 reads
+                        const int ahead = (nct - 1 - ct) < PF ? (nct - 1 - ct) : PF;
+                        if (ahead >= 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                        else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        s16x4* k4 = kb[ct % (PF + 1)];
+                        asm volatile("" : "+v"(k4[0]), "+v"(k4[1]), "+v"(k4[2]), "+v"(k4[3]));
+                        const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                        f32x16& o = O[ct >> 2][ct & 3];
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), o, 0, 0, 0);
+                        if (nct == 8) { p_step(2 * ct); p_step(2 * ct + 1); }
+                        else { p_step(4 * ct); p_step(4 * ct + 1); p_step(4 * ct + 2); p_step(4 * ct + 3); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                pa[0] = pn[0];
+                pa[1] = pn[1];
+                __builtin_amdgcn_s_barrier();                              // every wave is done with slot t
+                slot_cur = slot_cur == NB - 1 ? 0 : slot_cur + 1;
+            }
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s < ncs) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int C = (cb + s) * 4 + c;                         // column tile of the full row
                     const int slab = C >> 4, cl = C & 15;
                     const int nct = min(16, NSEG * 4 - 16 * slab);
                     uint4* dst = o_part + slab * slab_stride + ((long)grp * (Bpad / 32) + wb) * (long)(nct * 2 * 64) + lane;
@@ -1512,7 +1762,7 @@ FlashPlan plan(int B, int K) {
 
 }  // namespace
 
-static int wide_pv_lds(int nseg) { const int nb = 163840 / (nseg * 4096); return (nb > 6 ? 6 : nb) * nseg * 4096; }
+static int wide_pv_lds(int cseg) { const int nb = 163840 / (cseg * 4096); return (nb > 6 ? 6 : nb) * cseg * 4096; }
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
 static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
 
@@ -1548,7 +1798,9 @@ void set_lds_attrs() {
 #define MOMA_SET_WIDE(NS, PS) (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<NS, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PS * 8192)
     MOMA_SET_WIDE(5, 5); MOMA_SET_WIDE(6, 6); MOMA_SET_WIDE(8, 4); MOMA_SET_WIDE(10, 5); MOMA_SET_WIDE(12, 6);
 #undef MOMA_SET_WIDE
-#define MOMA_SET_WPV(NS) (void)hipFuncSetAttribute((const void*)infonce_wide_pv_kernel<NS, MOMA_K2_WIDE_NRW>, hipFuncAttributeMaxDynamicSharedMemorySize, wide_pv_lds(NS))
+#define MOMA_SET_WPV(NS)                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)infonce_wide_pv_kernel<NS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, wide_pv_lds(NS)); \
+    (void)hipFuncSetAttribute((const void*)infonce_wide_pv2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384)
     MOMA_SET_WPV(5); MOMA_SET_WPV(6); MOMA_SET_WPV(8); MOMA_SET_WPV(10); MOMA_SET_WPV(12);
 #undef MOMA_SET_WPV
 }
@@ -1615,14 +1867,24 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         if (dq) {
             const bool wide_pv = nseg == 5 || nseg == 6 || nseg == 8 || nseg == 10 || nseg == 12;
             if (wide_pv) {
-                // one pass over all columns; key chunks grouped so that the grid is about one workgroup per CU
-                constexpr int NRW = MOMA_K2_WIDE_NRW;
-                const int nrb = p.Bpad / (32 * NRW);
-                int want = 256 / nrb;
+                // one pass; a workgroup takes all columns for 64 rows, or one 256-column range for 256 rows -- whichever moves
+                // fewer bytes from L2 to the CUs (keys x row blocks + scores  vs  keys + scores x column ranges); key chunks
+                // grouped so that the grid is about one workgroup per CU
+                const int ncr = (nseg + 1) / 2;
+                const long rb_all = (p.Bpad / 32 + 1) / 2, rb_rng = (p.Bpad / 32 + 7) / 8;
+                const double kbytes = (double)d * 2, sbytes = 4.0 * p.Bpad;          // per key: its row / its scores
+                bool ranges = kbytes * rb_rng + sbytes * ncr < kbytes * rb_all + sbytes;
+                if (const char* e = getenv("MOMA_K2_WIDE_PV")) ranges = e[0] == 'r';      // (diagnostic override: "ranges" / "all")
+                const int nj = ranges ? (int)rb_rng * ncr : (int)rb_all;
+                int want = 256 / nj;
                 if (want < 1) want = 1;
                 cg = (p.nchunk + want - 1) / want;
                 const int ngroups = (p.nchunk + cg - 1) / cg;
-#define MOMA_WIDE_PV(NS) hipLaunchKernelGGL((infonce_wide_pv_kernel<NS, NRW>), dim3(nrb * ngroups), dim3(256 * NRW), wide_pv_lds(NS), st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16))
+#define MOMA_WIDE_PV(NS)                                                                                                      \
+                do {                                                                                                          \
+                    if (ranges) hipLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), 4 * 16384, st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16)); \
+                    else hipLaunchKernelGGL((infonce_wide_pv_kernel<NS, NS>), dim3(nj * ngroups), dim3(512), wide_pv_lds(NS), st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16)); \
+                } while (0)
                 if (nseg == 5) MOMA_WIDE_PV(5); else if (nseg == 6) MOMA_WIDE_PV(6); else if (nseg == 8) MOMA_WIDE_PV(8);
                 else if (nseg == 10) MOMA_WIDE_PV(10); else MOMA_WIDE_PV(12);
 #undef MOMA_WIDE_PV
