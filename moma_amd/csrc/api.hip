@@ -234,11 +234,13 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     float* dqkv = dP + (fused ? (size_t)H * N : (size_t)H * N * N);
     GemmArgs g;
     // proj: dWproj = dy^T a ; dbproj = colsum(dy) ; dA = dy Wproj
+    bool db_done = false;
     if (dw_proj) {
         g = gemm(dy, attn_out, dw_proj, d, d, N, d, d, d, 1, 1, 1.f, prec);
+        if (db_proj && gemm_fuses_colsum(g)) { g.colsum_a = db_proj; db_done = true; }       // the bias gradient rides along
         MOMA_TRY(launch_gemm(g, st));
     }
-    if (db_proj) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
+    if (db_proj && !db_done) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
     g = gemm(dy, w_proj, dA, N, d, d, d, d, d, 0, 1, 1.f, prec);
     MOMA_TRY(launch_gemm(g, st));
     if (fused) {
@@ -264,11 +266,13 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
         MOMA_TRY(launch_gemm(g, st));
     }
     // qkv linear: dWqkv = dqkv^T x ; dbqkv = colsum(dqkv) ; dx = dqkv Wqkv
+    db_done = false;
     if (dw_qkv) {
         g = gemm(dqkv, x, dw_qkv, 3 * d, d, N, 3L * d, d, d, 1, 1, 1.f, prec);
+        if (db_qkv && gemm_fuses_colsum(g)) { g.colsum_a = db_qkv; db_done = true; }
         MOMA_TRY(launch_gemm(g, st));
     }
-    if (db_qkv) MOMA_TRY(launch_colsum(dqkv, db_qkv, N, 3 * d, 3L * d, st));
+    if (db_qkv && !db_done) MOMA_TRY(launch_colsum(dqkv, db_qkv, N, 3 * d, 3L * d, st));
     if (dx) {
         g = gemm(dqkv, w_qkv, dx, N, d, 3 * d, 3L * d, d, d, 0, 1, 1.f, prec);
         MOMA_TRY(launch_gemm(g, st));

@@ -62,8 +62,11 @@ struct GemmArgs {
     int atomic;          // 1: atomicAdd into C
     int b_dtype;         // MOMA_DT_*
     int prec;            // MOMA_PREC_*
+    float* colsum_a;     // nullable: also write sum_k A(m,k) for every m (the bias gradient next to dW = dY^T X); only honoured
+                         // where gemm_fuses_colsum(args) holds, zero-initialised by value-initialisation otherwise ignored
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+bool gemm_fuses_colsum(const GemmArgs& a);     // true: launch_gemm fills a.colsum_a itself (no separate column-sum launch)
 
 // ---- row-wise helpers (rowops.hip) ---------------------------------------------------------------
 hipError_t launch_softmax_rows(float* s, long rows, int cols, hipStream_t st);

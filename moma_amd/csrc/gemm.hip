@@ -207,6 +207,7 @@ namespace {
 template <bool TRA, bool TRB>
 __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
     __shared__ float red[4][16][64];
+    __shared__ float csum[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r32 = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -217,6 +218,9 @@ __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // sum_k A(m, k) of this tile's 32 rows next to the product (the bias gradient beside dW = dY^T X): first column tile only
+    const bool want_cs = TRA && g.colsum_a != nullptr && blockIdx.x == 0;
+    float cs = 0.f;
     constexpr int CH = 8;                                           // k-steps in flight per chunk
     for (int c0 = 0; c0 < ns; c0 += CH) {
         float fa[CH][8], fb[CH][8];
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             if (c0 + s < ns) {
+                if (want_cs) cs += ((fa[s][0] + fa[s][1]) + (fa[s][2] + fa[s][3])) + ((fa[s][4] + fa[s][5]) + (fa[s][6] + fa[s][7]));
                 const bf16x8 a = bf16x8{(__bf16)fa[s][0], (__bf16)fa[s][1], (__bf16)fa[s][2], (__bf16)fa[s][3],
                                         (__bf16)fa[s][4], (__bf16)fa[s][5], (__bf16)fa[s][6], (__bf16)fa[s][7]};
                 const bf16x8 b = bf16x8{(__bf16)fb[s][0], (__bf16)fb[s][1], (__bf16)fb[s][2], (__bf16)fb[s][3],
@@ -258,7 +263,13 @@ __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    csum[wave][lane] = cs;
     __syncthreads();
+    if (want_cs && threadIdx.x < 32 && m0 + (int)threadIdx.x < g.M) {                // fixed order: K quarters, lane halves
+        const int r = threadIdx.x;
+        g.colsum_a[m0 + r] = (((csum[0][r] + csum[0][r + 32]) + (csum[1][r] + csum[1][r + 32])) +
+                              ((csum[2][r] + csum[2][r + 32]) + (csum[3][r] + csum[3][r + 32])));
+    }
     // D layout of the 32 x 32 tile: column = lane & 31, row = 8*(r>>2) + 4*(lane>>5) + (r&3); the K quarters in a fixed order
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -320,6 +331,8 @@ void launch_tm(const GemmArgs& a, hipStream_t s) {
     }
 }
 }  // namespace
+
+bool gemm_fuses_colsum(const GemmArgs& a) { return a.transA && a.alpha == 1.f && linear_ksplit_ok(a); }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
