@@ -1635,7 +1635,23 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         const int b = row_of(rr);
         const bool live = b < B;
         const int bb = live ? b : B - 1;
+        // The statistics are three dependent sweeps (positive logit; maxima; weights and sum): with up to 128 chunks every
+        // partial a lane needs is requested up front, next to the q / k rows, so the block pays ONE global round trip, not three
+        // (the kernel is latency-bound: 6.5 us of its 13.9 were this prologue).
+        constexpr int MC = 4;
+        const bool small = nchunk <= 32 * MC;
+        float mv[MC], xv[MC], lv[MC];
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = l32 + 32 * i;
+            const bool ok = small && c < nchunk;
+            const long o = (long)(ok ? c : 0) * Bpad + bb;
+            mv[i] = ok ? m_part[o] : NEG_BIG;
+            xv[i] = ok ? x_part[o] : NEG_BIG;
+            lv[i] = ok ? l_part[o] : 0.f;
+        }
         float s = 0.f;                                                   // positive logit
+#pragma unroll 4
         for (int c = l32 * 4; c < D; c += 128) {
             const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);
             const float4 ka = *reinterpret_cast<const float4*>(k + (long)bb * D + c);
@@ -1644,17 +1660,34 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         const float s0 = sum32(s) * inv_T;
         const float s0l = s0 * LOG2E;
         float M = NEG_BIG, X = NEG_BIG;
-        for (int c = l32; c < nchunk; c += 32) {
-            M = fmaxf(M, m_part[(long)c * Bpad + bb]);
-            X = fmaxf(X, x_part[(long)c * Bpad + bb]);
+        if (small) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) { M = fmaxf(M, mv[i]); X = fmaxf(X, xv[i]); }
+        } else {
+            for (int c = l32; c < nchunk; c += 32) {
+                M = fmaxf(M, m_part[(long)c * Bpad + bb]);
+                X = fmaxf(X, x_part[(long)c * Bpad + bb]);
+            }
         }
         M = fmaxf(max32(M), s0l);
         X = max32(X);
         float L = 0.f;
-        for (int c = l32; c < nchunk; c += 32) {
-            const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
-            if (cg == 1) wts[c][rr] = w;
-            L += w * l_part[(long)c * Bpad + bb];
+        if (small) {
+#pragma unroll
+            for (int i = 0; i < MC; ++i) {
+                const int c = l32 + 32 * i;
+                if (c < nchunk) {
+                    const float w = exp2f(mv[i] - M);
+                    if (cg == 1) wts[c][rr] = w;
+                    L += w * lv[i];
+                }
+            }
+        } else {
+            for (int c = l32; c < nchunk; c += 32) {
+                const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
+                if (cg == 1) wts[c][rr] = w;
+                L += w * l_part[(long)c * Bpad + bb];
+            }
         }
         if (cg > 1) {
             // O partials per GROUP of cg key chunks (wide P.K pass), relative to the largest reference of the group
