@@ -374,7 +374,10 @@ def main():
                                      "note": "launch / latency bound at N = batch (0.67 GFLOP per module call): the in-kernel "
                                              "matrix-pipe share is in pmc.mha_core_*"}
         roof["other"] = other
-        roof.update({"kernel": "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)",
+        kname = ("infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)" if d <= 512 else
+                 "infonce_wide_scores_kernel + infonce_wide_pv2_kernel (K2 over a wide queue, d > 512: the two passes over the queue; "
+                 "like the one-pass line the Q pre-pack in front and the combine behind are in whole_call_ms only)")
+        roof.update({"kernel": kname,
                      "ms_per_launch": round(k2_ms, 4), "whole_call_ms": round(k2_call_ms, 4),
                      "algorithmic_bytes": bytes_, "algorithmic_flops": flops,
                      "hbm_frac": round(bytes_ / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

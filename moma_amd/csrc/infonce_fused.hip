@@ -878,8 +878,9 @@ template <int NSEG, int PSEG>
 __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4* __restrict__ qpack,
                                                                      const bf16_raw* __restrict__ queue, int B, int K, int nbt,
                                                                      int nchunk, int tiles_per_chunk, int Bpad,
-                                                                     float* __restrict__ xs, float* __restrict__ m_part,
-                                                                     float* __restrict__ l_part, float* __restrict__ x_part) {
+                                                                     uint4* __restrict__ ps, float* __restrict__ m_part,
+                                                                     float* __restrict__ l_part, float* __restrict__ x_part,
+                                                                     float* __restrict__ r_part) {
     static_assert(NSEG % PSEG == 0 && PSEG <= 6, "phases tile the row; 3 phase buffers fit 160 KiB");
     constexpr int KS = NSEG * 8;                    // k-steps of a complete score tile
     constexpr int NA = KS < 64 ? KS : 64;           // Q fragments kept in AGPRs
@@ -945,16 +946,18 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
     };
     // global phase index g = (tile - t0) * NPH + p lives in buffer g % 3
     const int nph_total = (t1 - t0) * NPH;
-    {
-        // phases 0 and 1 up front
+    auto issue_first_phases = [&]() __attribute__((always_inline)) {          // phases 0 and 1 up front
+        int tb = t0;
+        asm volatile("" : "+s"(tb));                   // (opaque: the two sweeps do not share hoisted source addresses)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             if (g < nph_total) {
 #pragma unroll
-                for (int i = 0; i < PPP; ++i) dma_piece_ph(i, t0 + g / NPH, g % NPH, smem + g * PH_BYTES);
+                for (int i = 0; i < PPP; ++i) dma_piece_ph(i, tb + g / NPH, g % NPH, smem + g * PH_BYTES);
             }
         }
-    }
+    };
+    issue_first_phases();
     const int a_off = n * 256 + ((swz(n) ^ h) << 4);
     f32x4 kf[RD];
     unsigned aa[8];
@@ -979,6 +982,14 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
     for (int f = 0; f < NV; ++f) asm volatile("" : "+v"(qv[f]));
     __builtin_amdgcn_s_barrier();
 
+    // The scores leave as P~ = bf16(2^(x - r)) in MFMA A-operand order (half the bytes of fp32 scores, and pass 2 needs no
+    // exponential): r = an INTEGER reference per (chunk, row) -- ceil(row max of the chunk's first tile) + REF_MARGIN -- so that pass 2
+    // moves a tile to its chunk group's reference by an exact power of two.  A score more than OVERFLOW_THR above r (P~ could
+    // overflow) makes the workgroup repeat its chunk with r = ceil(true row maximum), which cannot (rare, workgroup-uniform).
+    float r_ref = 0.f;
+    int ovf = 0;
+    auto sweep = [&](auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     int bi = 0;                                      // buffer of the current phase
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
@@ -997,6 +1008,12 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             }
 #pragma unroll
             for (int j = 0; j < RD; ++j) rd(j);
+            // refill requested at the TOP of the phase: the kernel is bound by (bytes in flight) / (memory latency), and pieces of
+            // phase g+2 spread over the MFMAs of phase g are in flight half a phase less (measured: 69 -> 64 us forward-only)
+            if (refill) {
+#pragma unroll
+                for (int i = 0; i < PPP; ++i) dma_piece_ph(i, rt, rp, rbuf);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < PSTEPS; ++j) {
@@ -1011,7 +1028,6 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
                 else
                     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[j % RD]), "v"(qv[f >= NA ? f - NA : 0]));
                 if (j + RD < PSTEPS) rd(j + RD);
-                if ((j & 3) == 1 && refill) dma_piece_ph(j >> 2, rt, rp, rbuf);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (p == NPH - 1) {
@@ -1022,24 +1038,39 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
                     for (int r = 0; r < 16; ++r)
                         if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
                 }
-                float4* xa = reinterpret_cast<float4*>(xs + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 16);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) xa[g4] = make_float4(x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]);
                 float tm = x[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tm = fmaxf(tm, x[r]);
-                const float mn = fmaxf(m_run, tm);
-                float ps = 0.f;
+                if constexpr (FIRST) {
+                    if (t == t0) r_ref = ceilf(fmaxf(tm, other_half(tm))) + REF_MARGIN;       // (row-uniform: both lane halves)
+                    ovf |= (tm - r_ref > OVERFLOW_THR) ? 1 : 0;
+                    const float mn = fmaxf(m_run, tm);
+                    float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(x[r] - mn);
-                l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + ps;
-                m_run = mn;
+                    for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(x[r] - mn);
+                    l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + sum;
+                    m_run = mn;
+                }
+                uint4 w0, w1;
+                {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = __builtin_amdgcn_exp2f(x[2 * i] - r_ref), b = __builtin_amdgcn_exp2f(x[2 * i + 1] - r_ref);
+                        pk[i] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+                    }
+                    w0 = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    w1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                }
+                uint4* pd = ps + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 2;
+                pd[0] = w0;
+                pd[1] = w1;
             }
             // the next phase must have landed.  Certainly younger than its pieces: this phase's refill pieces and, behind a tile's
             // last phase, the 4 score stores just issued (the previous tile's stores may be younger too: not counted, i.e.
             // waited for -- they are a phase old)
             if (refill) {
-                if (p == NPH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP + 4) : "memory");
+                if (p == NPH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP + 2) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1048,258 +1079,32 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             bi = bi == 2 ? 0 : bi + 1;
         }
     }
+    };
+    sweep(std::true_type{});
     // ---- per (chunk, row): the two lane halves hold disjoint keys of the same row
     const float mo = other_half(m_run), lo = other_half(l_run);
     const float M = fmaxf(m_run, mo);
     const float L = l_run * __builtin_amdgcn_exp2f(m_run - M) + lo * __builtin_amdgcn_exp2f(mo - M);
+    {
+        int* wflag = reinterpret_cast<int*>(smem + 3 * PH_BYTES);               // 4 words behind the phase buffers
+        const int any = __any(ovf) ? 1 : 0;
+        if (lane == 0) wflag[wave] = any;
+        __syncthreads();
+        if ((wflag[0] | wflag[1] | wflag[2] | wflag[3]) != 0) {
+            r_ref = ceilf(M);                                                    // true row maximum of the chunk
+            __syncthreads();
+            issue_first_phases();
+            if (nph_total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            sweep(std::false_type{});
+        }
+    }
     if (h == 0) {
         m_part[prow + n] = M;
         l_part[prow + n] = L;
         x_part[prow + n] = M;
-    }
-}
-
-// ---- wide queues, P.K in ONE pass over all columns (the scores are read ONCE) --------------------------------------------------
-// Workgroup = NRW row-waves (32 query rows each) x 4 column slices; wave (rw, sl) owns O[32 rows x its slice] -- the NSEG
-// segments of 128 columns are dealt 3/3/2/2-style to the slices -- so no wave holds more than 3 x 64 accumulator registers and
-// the finished fp32 scores of a row-wave are read once instead of once per 512-column slab.  Key tiles are 16 keys high (ONE
-// k-step of P.K; 32 keys x d bf16 would not leave room for a ring at d = 1280): 3 ring slots of NSEG x [16 keys][128 cols] with
-// the same swizzled image as the 32-key tiles.  P = 2^(x - reference) with the reference of the (row, chunk GROUP) = max of the
-// group's chunk maxima from the score pass: never above 1, no rescue path; the combine kernel weighs the groups.
-// Partials go out in the column-slab layout of the slab passes (the combine kernel reads both).
-template <int NSEG, int CSEG>
-__global__ __launch_bounds__(512, 1) void infonce_wide_pv_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
-                                                                 int tiles_per_chunk, int cg, int Bpad,
-                                                                 const float* __restrict__ xs,
-                                                                 const float* __restrict__ m_part,
-                                                                 uint4* __restrict__ o_part, long slab_stride) {
-    // CSEG = segments of the workgroup's COLUMN RANGE.  CSEG == NSEG: all columns, 2 row-waves x 4 slices (the keys cross
-    // L2 -> CU once per 64 query rows, the scores once).  CSEG == 2: one 256-column range per workgroup, 8 row-waves x 1 slice
-    // (the keys cross once per 256 rows, the scores once per column range) -- less traffic in all when d/256 < rows/64.
-    constexpr int NWAVES = 8;
-    constexpr int NSL = CSEG == NSEG ? 4 : 1;       // column slices inside the workgroup
-    constexpr int NRW = NWAVES / NSL;               // row-waves (32 query rows each) of the workgroup
-    constexpr int NCR = (NSEG + CSEG - 1) / CSEG;   // column ranges of the row
-    constexpr int NSW = (CSEG + NSL - 1) / NSL;     // segments of the widest slice
-    constexpr int T16_BYTES = CSEG * 4096;          // 16 keys x the range's columns, bf16
-    constexpr int NB = (163840 / T16_BYTES) > 6 ? 6 : (163840 / T16_BYTES);     // ring slots (d = 1280, all columns: the 160 KiB)
-    constexpr int SD = NB - 1;                      // tiles requested ahead (keys by LDS-DMA, scores into registers)
-    constexpr int NPT = (CSEG * 4 + NWAVES - 1) / NWAVES;     // LDS-DMA pieces per wave and tile (1 KiB: 4 rows of a segment)
-    constexpr int OPT = NPT + 2;                    // vector-memory operations per wave and tile (2 score loads + the pieces)
-    static_assert(NB >= 3 && OPT * (SD - 1) <= 63, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int widx = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rw = widx / NSL, sl = widx % NSL;
-    const int wq = widx >> 2, wr = widx & 3;          // LDS-DMA role of the wave: piece i = (segment 2i + wq, row group wr)
-    const int n = lane & 31, h = lane >> 5;
-    const int ngroups = (nchunk + cg - 1) / cg;
-    const int nrb = (Bpad / 32 + NRW - 1) / NRW;
-    const int nj = nrb * NCR;                         // workgroups per key group: (row block, column range)
-    // the workgroups of one key group are 8 block ids apart when that tiles (same XCD: one L2 fetch of the keys and scores)
-    int jj, grp;
-    {
-        const int id = blockIdx.x;
-        if ((ngroups & 7) == 0) {
-            const int g = id / (8 * nj), r = id % (8 * nj);
-            jj = r >> 3;
-            grp = g * 8 + (r & 7);
-        } else {
-            jj = id % nj;
-            grp = id / nj;
-        }
-    }
-    const int rb = jj / NCR, cr = jj % NCR;
-    const int wb = min(rb * NRW + rw, Bpad / 32 - 1);  // 32-row wave block of this wave (a wave past the rows repeats the last one)
-    const bool live = rb * NRW + rw < Bpad / 32;
-    const int ntiles = (K + KT - 1) / KT;
-    const int c0 = grp * cg, c1 = min(c0 + cg, nchunk);
-    const int u0 = 2 * c0 * tiles_per_chunk;                              // 16-key tiles [u0, u1)
-    const int u1 = min(2 * min(c1 * tiles_per_chunk, ntiles), (K + 15) / 16);
-    // column range of the workgroup: segments [cb, cb + ncs); slice of this wave inside it: segments [sb, sb + nsw) of the range
-    const int cb = cr * CSEG, ncs = min(CSEG, NSEG - cb);
-    const int base = ncs / NSL, rem = ncs % NSL;
-    const int nsw = base + (sl < rem ? 1 : 0);
-    const int sb = sl * base + min(sl, rem);
-    const unsigned pitch = NSEG * 256;
-
-    float mref = NEG_BIG;
-    for (int c = c0; c < c1; ++c) mref = fmaxf(mref, m_part[(long)c * Bpad + wb * 32 + n]);
-
-    // ---- finished scores of 16-key tile u (half of a 32-key score tile in register order): 2 x 16 B per lane by inline asm
-    //      into a register ring, SD tiles ahead like the keys, counted by hand (LDS-DMA and ordinary loads share vmcnt; at
-    //      the first use of an ordinary load hipcc would drain the whole ring)
-    f32x4 sa[SD], sb4[SD];
-    const unsigned xlane = lane * 64;                                    // 16 floats per lane and 32-key tile, register order
-    auto load_scores = [&](int u, f32x4& d0, f32x4& d1) __attribute__((always_inline)) {
-        const char* xb = reinterpret_cast<const char*>(xs) + (((long)wb * ntiles + (u >> 1)) * 4096 + 32 * (u & 1));   // wave-uniform
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
-                     : "=&v"(d0), "=&v"(d1) : "v"(xlane), "s"(xb) : "memory");
-    };
-    // ---- LDS-DMA: piece pc of a tile = (segment pc>>2, row group pc&3); source lane term for row group rg = term0 ^ (rg << 4)
-    const int rl = lane >> 4, s16 = lane & 15;
-    const unsigned term0 = (unsigned)(rl * pitch + ((s16 ^ (rl << 2)) << 4));
-    // The LDS-DMA of this kernel is inline asm (scalar base + one lane offset + immediates; M0 written in the statement that
-    // reads it; no LDS-DMA builtin anywhere in the kernel, so hipcc has no M0 of its own to keep): the builtin cost ~12
-    // instructions per piece, and two waves per SIMD share the issue slots.  Wait states by hand: an SGPR written by the SALU
-    // code in front of the statement needs 5 states before a vector-memory instruction reads it as base (s_add + s_nop 3),
-    // M0 one state before the LDS-DMA.
-    // With 8 waves piece i of wave (rw, sl) is (segment 2i + rw, row group sl): ONE lane term per wave.
-    constexpr bool EVEN = (CSEG * 4) % NWAVES == 0;
-    const unsigned voff = term0 ^ (unsigned)(wr << 4);
-    auto dma_tile16 = [&](int u, unsigned lds_slot) __attribute__((always_inline)) {       // lds_slot: LDS byte address of the slot
-        const long key0 = (long)u * 16;
-        if (EVEN && ncs == CSEG && key0 + 16 <= K) {
-            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + ((cb + wq) * 256 + wr * 4 * (int)pitch);
-            const unsigned dst = lds_slot + wq * 4096 + wr * 1024;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2"
-                             :: "v"(voff), "s"(src), "n"(i * 512), "s"(dst), "n"(i * 8192 - i * 512) : "memory", "scc");   // (the immediate offset moves the LDS destination too)
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            int pc = i * NWAVES + widx;
-            pc = pc < ncs * 4 ? pc : 0;                                   // (padding pieces reload piece 0: equal counts per wave)
-            const int sg = pc >> 2, rg = pc & 3;
-            const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (cb + sg) * 256;
-            unsigned off = term0 ^ (unsigned)(rg << 4);
-            if (key0 + 16 > K) {                    // the queue's last, partial tile: clamp rows past K (their P is 0)
-                const int row = min(rg * 4 + rl, (int)(K - 1 - key0));
-                off = off - (unsigned)rl * pitch + (unsigned)row * pitch;
-            } else {
-                src += rg * 4 * (long)pitch;
-            }
-            const unsigned dst = lds_slot + sg * 4096 + rg * 1024;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(off), "s"(src), "s"(dst) : "memory");
-        }
-    };
-    // tiles are requested strictly in order, each as (2 score loads, NPT pieces): "tile v and everything older has landed"
-    // is s_waitcnt vmcnt(OPT x tiles requested after v)
-    auto wait_younger_tiles = [&](int j) __attribute__((always_inline)) {
-        switch (j) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPT) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT > 63 ? 63 : 2 * OPT) : "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPT > 63 ? 63 : 3 * OPT) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * OPT > 63 ? 63 : 4 * OPT) : "memory"); break;
-        }
-    };
-
-    // prologue: tiles u0 .. u0+SD-1 into slots 0 .. SD-1
-    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
-#pragma unroll
-    for (int j = 0; j < SD; ++j)
-        if (u0 + j < u1) {
-            load_scores(u0 + j, sa[j], sb4[j]);
-            dma_tile16(u0 + j, lds0 + j * T16_BYTES);
-        }
-
-    // O = 0 by MFMAs on zero operands with the inline-constant accumulator (see the one-pass kernel)
-    f32x16 O[NSW][4];
-    {
-        bf16x8 zq = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-#pragma unroll
-        for (int s = 0; s < NSW; ++s)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                asm volatile("" : "+v"(zq));
-                O[s][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zq, zq, z, 0, 0, 0);
-            }
-    }
-    // transposed-read lane offsets (B operand: 16 keys x 32 columns), as in the one-pass kernel
-    int b_off;
-    {
-        const int i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
-        const int e = (2 * g2 + (p >> 1)) ^ h;
-        b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
-    }
-    wait_younger_tiles(max(min(u0 + SD - 1, u1 - 1) - u0, 0));           // tile u0 landed
-    __builtin_amdgcn_s_barrier();
-
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    int slot_cur = 0;                                                     // ring slot of tile u
-#pragma unroll 1
-    for (int ub = u0; ub < u1; ub += SD) {
-#pragma unroll
-        for (int j = 0; j < SD; ++j) {                                    // (unrolled: the score ring is indexed statically)
-            const int u = ub + j;
-            if (u < u1) {
-                asm volatile("" : "+v"(sa[j]), "+v"(sb4[j]));
-                float x[8] = {sa[j][0], sa[j][1], sa[j][2], sa[j][3], sb4[j][0], sb4[j][1], sb4[j][2], sb4[j][3]};
-                // tile u+SD: scores into the registers just read, keys into the slot of tile u-1 (free since the last barrier)
-                const int slot_free = slot_cur == 0 ? NB - 1 : slot_cur - 1;
-                if (u + SD < u1) {
-                    load_scores(u + SD, sa[j], sb4[j]);
-                    dma_tile16(u + SD, lds0 + slot_free * T16_BYTES);
-                }
-                if ((u + 1) * 16 > K) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (u * 16 + (i & 3) + 8 * (i >> 2) + 4 * h >= K) x[i] = NEG_BIG;
-                }
-                bf16x8 pa;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) pa[i] = (__bf16)__builtin_amdgcn_exp2f(x[i] - mref);
-                const unsigned lb = lds0 + slot_cur * T16_BYTES + b_off + sb * 4096;
-#pragma unroll
-                for (int s = 0; s < NSW; ++s) {
-                    if (s < nsw) {                                           // (wave-uniform)
-                        s16x4 kb[4][2];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kb[c][0]) : "v"(lb ^ (c << 6)), "i"(s * 4096) : "memory");
-                            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(kb[c][1]) : "v"(lb ^ ((c << 6) | 32)), "i"(s * 4096 + 2048) : "memory");
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (c == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                            else if (c == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                            else if (c == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            asm volatile("" : "+v"(kb[c][0]), "+v"(kb[c][1]));
-                            const s16x8 k0 = __builtin_shufflevector(kb[c][0], kb[c][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                            O[s][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, k0), O[s][c], 0, 0, 0);
-                        }
-                    }
-                }
-                // tile u+1 (keys and scores) must have landed; the tiles requested after it may stay in flight
-                if (u + SD < u1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SD - 1) * OPT) : "memory");     // (steady state)
-                else wait_younger_tiles(max(u1 - 1 - (u + 1), 0));
-                __builtin_amdgcn_s_barrier();                                // ... and every wave is done with slot u
-                slot_cur = slot_cur == NB - 1 ? 0 : slot_cur + 1;
-            }
-        }
-    }
-
-    // ---- partial O of (group, wave block): slab layout of the slab passes (16 column tiles per 512-column slab)
-    if (live) {
-#pragma unroll
-        for (int s = 0; s < NSW; ++s) {
-            if (s < nsw) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int C = (cb + sb + s) * 4 + c;                    // column tile of the full row
-                    const int slab = C >> 4, cl = C & 15;
-                    const int nct = min(16, NSEG * 4 - 16 * slab);
-                    uint4* dst = o_part + slab * slab_stride + ((long)grp * (Bpad / 32) + wb) * (long)(nct * 2 * 64) + lane;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        uint4 v;
-                        v.x = (unsigned)f32_to_bf16(O[s][c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 1]) << 16);
-                        v.y = (unsigned)f32_to_bf16(O[s][c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 3]) << 16);
-                        v.z = (unsigned)f32_to_bf16(O[s][c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 5]) << 16);
-                        v.w = (unsigned)f32_to_bf16(O[s][c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 7]) << 16);
-                        dst[(cl * 2 + g) * 64] = v;
-                    }
-                }
-            }
-        }
+        r_part[prow + n] = r_ref;
     }
 }
 
@@ -1308,18 +1113,21 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv_kernel(const bf16_raw*
 // 256 rows, the scores once per range; wave w owns O[32 rows x 256 columns] = 128 accumulator registers (two waves per SIMD).
 // 32-key tiles in the standard swizzled image (2 segments x 8 KiB per ring slot, 6 slots), so one workgroup barrier serves 16
 // MFMAs per wave; keys (2 LDS-DMA pieces per wave) and scores (4 x 16 B per lane, register ring) are requested SD tiles ahead by
-// inline asm and counted by hand.  P of tile t+1 is formed BEFORE the barrier that ends tile t (the scores are in registers), in
-// the shadow of tile t's last MFMAs; the transposed reads run two column tiles ahead of their MFMAs (hand-counted lgkmcnt).
-// Reference of P and partial layout as in the kernel above.
+// inline asm and counted by hand.  P arrives as bf16 relative to its CHUNK's integer reference (pass 1); the workgroup covers a
+// GROUP of cg chunks and accumulates relative to R = the largest reference of the group, so a tile of chunk c is scaled by the
+// exact power of two 2^(r_c - R) <= 1 (unpack, multiply, repack: no exponential, no rounding) -- skipped when the whole wave has
+// r_c == R.  P of tile t+1 is prepared in the shadow of tile t's MFMAs; the transposed reads run two column tiles ahead of their
+// MFMAs (hand-counted lgkmcnt).  Partials per (group, wave block) in the column-slab layout the combine kernel reads.
 template <int NSEG>
 __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw* __restrict__ queue, int B, int K, int nchunk,
                                                                   int tiles_per_chunk, int cg, int Bpad,
-                                                                  const float* __restrict__ xs, const float* __restrict__ m_part,
+                                                                  const uint4* __restrict__ ps, const float* __restrict__ r_part,
                                                                   uint4* __restrict__ o_part, long slab_stride) {
     constexpr int NCR = (NSEG + 1) / 2;             // column ranges of the row
     constexpr int SLOT = 2 * 8192;                  // 32 keys x 256 columns bf16
     constexpr int NB = 4, SD = 3;                   // ring slots; tiles requested ahead (scores: 16 registers per tile)
-    constexpr int OPT = 6;                          // vector-memory operations per wave and tile: 4 score loads + 2 pieces
+    constexpr int OPT = 4;                          // vector-memory operations per wave and tile: 2 loads of P + 2 pieces
+    constexpr int CGMAX = 8;                        // chunks per group (the launcher keeps cg <= CGMAX)
     constexpr int PF = 2;                           // column tiles of transposed reads in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -1343,17 +1151,22 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
     const int cb = cr * 2, ncs = min(2, NSEG - cb);
     const unsigned pitch = NSEG * 256;
 
-    float mref = NEG_BIG;
-    for (int c = c0; c < c1; ++c) mref = fmaxf(mref, m_part[(long)c * Bpad + wb * 32 + n]);
+    // scale factors 2^(r_c - R) of the group's chunks, per lane (= per query row), kept in LDS behind the ring
+    float* ftab = reinterpret_cast<float*>(smem + NB * SLOT) + w * (CGMAX * 64);
+    {
+        float R = NEG_BIG;
+        for (int c = c0; c < c1; ++c) R = fmaxf(R, r_part[(long)c * Bpad + wb * 32 + n]);
+        for (int c = c0; c < c1; ++c) ftab[(c - c0) * 64 + lane] = __builtin_amdgcn_exp2f(r_part[(long)c * Bpad + wb * 32 + n] - R);
+    }
 
-    // ---- scores of tile t: 16 floats per lane in register order
-    f32x4 sx[SD][4];
-    const unsigned xlane = lane * 64;
-    auto load_scores = [&](int t, f32x4 (&d)[4]) __attribute__((always_inline)) {
-        const char* xb = reinterpret_cast<const char*>(xs) + ((long)wb * ntiles + t) * 4096;          // wave-uniform
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:16\n\t"
-                     "global_load_dwordx4 %2, %4, %5 offset:32\n\tglobal_load_dwordx4 %3, %4, %5 offset:48"
-                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(xlane), "s"(xb) : "memory");
+    // ---- P~ of tile t: 16 bf16 per lane in A-operand order (8 packed registers)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 sx[SD][2];
+    const unsigned xlane = lane * 32;
+    auto load_scores = [&](int t, u32x4 (&d)[2]) __attribute__((always_inline)) {
+        const char* xb = reinterpret_cast<const char*>(ps) + ((long)wb * ntiles + t) * 2048;          // wave-uniform
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(xlane), "s"(xb) : "memory");
     };
     // ---- keys of tile t: wave w issues row group w (4 rows) of both segments (of segment 0 twice when the range has one)
     const int rl = lane >> 4, s16 = lane & 15;
@@ -1413,24 +1226,24 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
         const int e = (2 * g2 + (p >> 1)) ^ h;
         b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
     }
-    // P of a tile from its scores: register r = key (r&3) + 8*(r>>2) + 4h of the tile; registers 8s..8s+7 = A fragment of k-step s
-    auto make_p = [&](const f32x4 (&d)[4], int t, bf16x8 (&pa)[2]) __attribute__((always_inline)) {
-        float x[16];
+    // P of a tile: its packed words ARE the two A fragments (k-step s = words 4s..4s+3); moved to the group's reference by the
+    // exact factor f = 2^(r_c - R) of the tile's chunk unless the whole wave has f == 1
+    auto make_p = [&](const u32x4 (&d)[2], int t, bf16x8 (&pa)[2]) __attribute__((always_inline)) {
+        const float f = ftab[(t / tiles_per_chunk - c0) * 64 + lane];
+        unsigned wv[8] = {d[0][0], d[0][1], d[0][2], d[0][3], d[1][0], d[1][1], d[1][2], d[1][3]};
+        if (__any(f != 1.f)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = d[r >> 2][r & 3];
-        if ((t + 1) * KT > K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (t * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x[r] = NEG_BIG;
+            for (int i = 0; i < 8; ++i) {
+                const float lo = __uint_as_float(wv[i] << 16) * f, hi = __uint_as_float(wv[i] & 0xffff0000u) * f;
+                wv[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+            }
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pa[s][i] = (__bf16)__builtin_amdgcn_exp2f(x[8 * s + i] - mref);
+        pa[0] = __builtin_bit_cast(bf16x8, u32x4{wv[0], wv[1], wv[2], wv[3]});
+        pa[1] = __builtin_bit_cast(bf16x8, u32x4{wv[4], wv[5], wv[6], wv[7]});
     };
     bf16x8 pa[2];
     wait_younger_tiles(max(min(t0 + SD - 1, t1 - 1) - t0, 0));           // tile t0 landed
-    asm volatile("" : "+v"(sx[0][0]), "+v"(sx[0][1]), "+v"(sx[0][2]), "+v"(sx[0][3]));
+    asm volatile("" : "+v"(sx[0][0]), "+v"(sx[0][1]));
     make_p(sx[0], t0, pa);
     __builtin_amdgcn_s_barrier();
 
@@ -1482,15 +1295,11 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                 // tile t+1 (keys and scores, requested two iterations ago) has landed by now; the tiles requested after it stay
                 // in flight.  P(t+1) is formed in the shadow of this tile's MFMAs, 4 (or 2) scores per column tile.
                 wait_younger_tiles(max(min(t + SD, t1 - 1) - (t + 1), 0));
-                f32x4 (&nx)[4] = sx[(j + 1) % SD];
-                asm volatile("" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]));
+                u32x4 (&nx)[2] = sx[(j + 1) % SD];
+                asm volatile("" : "+v"(nx[0]), "+v"(nx[1]));
                 bf16x8 pn[2];
-                const bool tail = (t + 2) * KT > K;                       // tile t+1 reaches past K: its late keys get P = 0
-                auto p_step = [&](int r) __attribute__((always_inline)) {  // score register r of tile t+1
-                    float x = nx[r >> 2][r & 3];
-                    if (tail && (t + 1) * KT + (r & 3) + 8 * (r >> 2) + 4 * h >= K) x = NEG_BIG;
-                    pn[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(x - mref);
-                };
+                if (t + 1 < t1) make_p(nx, t + 1, pn);                     // (VALU work under this tile's MFMAs; no tail masking:
+                                                                           //  pass 1 stored P~ = 0 for keys past K)
 #pragma unroll
                 for (int ct = 0; ct < 8; ++ct) {
                     if (ct < nct) {
@@ -1507,8 +1316,6 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                         f32x16& o = O[ct >> 2][ct & 3];
                         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), o, 0, 0, 0);
                         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), o, 0, 0, 0);
-                        if (nct == 8) { p_step(2 * ct); p_step(2 * ct + 1); }
-                        else { p_step(4 * ct); p_step(4 * ct + 1); p_step(4 * ct + 2); p_step(4 * ct + 3); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1605,7 +1412,9 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq,
                                                                long slab_stride, int cg, int phase,
-                                                               float* __restrict__ rowstats) {
+                                                               float* __restrict__ rowstats,
+                                                               const float* __restrict__ ref_part) {
+    // ref_part: per (chunk, row) reference of the O partials when it is not m_part (wide rows: the integer references of pass 1)
     // phase 0: everything in one launch (every column-tile block repeats the row statistics: 16x at d = 512, cheap);
     // wide rows (40 column tiles at d = 1280): phase 1 = statistics + loss / lse / top-1, weights to `rowstats`; phase 2 = dq
     __shared__ __attribute__((aligned(16))) float wts[COMBINE_MAX_CHUNKS][8];
@@ -1678,22 +1487,22 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                 const int c = l32 + 32 * i;
                 if (c < nchunk) {
                     const float w = exp2f(mv[i] - M);
-                    if (cg == 1) wts[c][rr] = w;
+                    if (cg == 1 && ref_part == m_part) wts[c][rr] = w;
                     L += w * lv[i];
                 }
             }
         } else {
             for (int c = l32; c < nchunk; c += 32) {
                 const float w = exp2f(m_part[(long)c * Bpad + bb] - M);
-                if (cg == 1) wts[c][rr] = w;
+                if (cg == 1 && ref_part == m_part) wts[c][rr] = w;
                 L += w * l_part[(long)c * Bpad + bb];
             }
         }
-        if (cg > 1) {
+        if (cg > 1 || ref_part != m_part) {
             // O partials per GROUP of cg key chunks (wide P.K pass), relative to the largest reference of the group
             for (int j = l32; j * cg < nchunk; j += 32) {
                 float mg = NEG_BIG;
-                for (int c = j * cg; c < min((j + 1) * cg, nchunk); ++c) mg = fmaxf(mg, m_part[(long)c * Bpad + bb]);
+                for (int c = j * cg; c < min((j + 1) * cg, nchunk); ++c) mg = fmaxf(mg, ref_part[(long)c * Bpad + bb]);
                 wts[j][rr] = exp2f(mg - M);
             }
         }
@@ -1795,7 +1604,7 @@ FlashPlan plan(int B, int K) {
 
 }  // namespace
 
-static int wide_pv_lds(int cseg) { const int nb = 163840 / (cseg * 4096); return (nb > 6 ? 6 : nb) * cseg * 4096; }
+constexpr int WIDE_PV2_LDS = 4 * 16384 + 8 * 8 * 64 * 4;        // ring of 4 x (32 keys x 256 columns) + the scale-factor table
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
 static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
 
@@ -1810,7 +1619,7 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     const int ds = d > 512 ? 512 : d;                        // widest slab
     const int nslab = (d + 511) / 512;                       // one partial buffer per column slab
-    size_t bytes = (size_t)nslab * rows * ds * 2 + 3 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
+    size_t bytes = (size_t)nslab * rows * ds * 2 + 4 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
     if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 512       // score scratch
                           + (size_t)(p.Bpad / 8) * (p.nchunk * 8 + 16) * sizeof(float);           // row statistics of the combine
     return bytes;
@@ -1828,12 +1637,10 @@ void set_lds_attrs() {
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
     MOMA_SET_LDS(512); MOMA_SET_LDS(384); MOMA_SET_LDS(256); MOMA_SET_LDS(128);
 #undef MOMA_SET_LDS
-#define MOMA_SET_WIDE(NS, PS) (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<NS, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PS * 8192)
+#define MOMA_SET_WIDE(NS, PS) (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<NS, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PS * 8192 + 16)
     MOMA_SET_WIDE(5, 5); MOMA_SET_WIDE(6, 6); MOMA_SET_WIDE(8, 4); MOMA_SET_WIDE(10, 5); MOMA_SET_WIDE(12, 6);
 #undef MOMA_SET_WIDE
-#define MOMA_SET_WPV(NS)                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)infonce_wide_pv_kernel<NS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, wide_pv_lds(NS)); \
-    (void)hipFuncSetAttribute((const void*)infonce_wide_pv2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384)
+#define MOMA_SET_WPV(NS) (void)hipFuncSetAttribute((const void*)infonce_wide_pv2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_PV2_LDS)
     MOMA_SET_WPV(5); MOMA_SET_WPV(6); MOMA_SET_WPV(8); MOMA_SET_WPV(10); MOMA_SET_WPV(12);
 #undef MOMA_SET_WPV
 }
@@ -1849,7 +1656,8 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     float* m_part = (float*)ws;
     float* l_part = m_part + rows;
     float* x_part = l_part + rows;
-    uint4* o_part = (uint4*)(((uintptr_t)(x_part + rows) + 255) & ~(uintptr_t)255);
+    float* r_part = x_part + rows;                             // wide rows: integer references of the stored P (pass 1)
+    uint4* o_part = (uint4*)(((uintptr_t)(r_part + rows) + 255) & ~(uintptr_t)255);
     uint4* qpack = (uint4*)(((uintptr_t)((char*)o_part + rows * dsl * 2) + 255) & ~(uintptr_t)255);
     std::call_once(g_lds_attr_once, set_lds_attrs);
     const float scale_log2 = inv_T * 1.4426950408889634f;
@@ -1867,12 +1675,14 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * d * 2) + 255) & ~(uintptr_t)255);
         const int ntiles = (K + KT - 1) / KT;
         auto slab_width = [&](int col0) { const int rem = d - col0; return rem >= 512 ? 512 : rem; };   // 512.., then 384/256/128
-        if (ev_begin) (void)hipEventRecord(ev_begin, st);
+        // (the measurement events span the passes over the queue -- scores and P.K -- like the one-pass path, where they span the
+        //  flash kernel: the Q pre-pack in front and the combine behind are outside in both)
         const int nseg = d / 128;
 #define MOMA_WIDE_SCORES(NS, PS, DD)                                                                                          \
         do {                                                                                                                  \
             hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
-            hipLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192, st, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, xs, m_part, l_part, x_part); \
+            if (ev_begin) (void)hipEventRecord(ev_begin, st);                                                                 \
+            hipLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192 + 16, st, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, (uint4*)xs, m_part, l_part, x_part, r_part); \
         } while (0)
         if (nseg == 5) MOMA_WIDE_SCORES(5, 5, 640);
         else if (nseg == 6) MOMA_WIDE_SCORES(6, 6, 768);
@@ -1880,6 +1690,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         else if (nseg == 10) MOMA_WIDE_SCORES(10, 5, 1280);
         else if (nseg == 12) MOMA_WIDE_SCORES(12, 6, 1536);
         else {
+            if (ev_begin) (void)hipEventRecord(ev_begin, st);      // (slab passes: a pre-pack per slab sits between the passes)
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
                 const int D = slab_width(col0);
                 const SlabArgs sa{xs, nullptr, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
@@ -1897,27 +1708,21 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         }
 #undef MOMA_WIDE_SCORES
         int cg = 1;
+        const float* wide_ref = m_part;                        // reference of the O partials (the combine kernel's weights)
         if (dq) {
             const bool wide_pv = nseg == 5 || nseg == 6 || nseg == 8 || nseg == 10 || nseg == 12;
             if (wide_pv) {
-                // one pass; a workgroup takes all columns for 64 rows, or one 256-column range for 256 rows -- whichever moves
-                // fewer bytes from L2 to the CUs (keys x row blocks + scores  vs  keys + scores x column ranges); key chunks
-                // grouped so that the grid is about one workgroup per CU
+                // column ranges of 256 columns x 256 rows per workgroup; key chunks grouped (<= 8 per group) so that the grid is
+                // about one workgroup per CU
                 const int ncr = (nseg + 1) / 2;
-                const long rb_all = (p.Bpad / 32 + 1) / 2, rb_rng = (p.Bpad / 32 + 7) / 8;
-                const double kbytes = (double)d * 2, sbytes = 4.0 * p.Bpad;          // per key: its row / its scores
-                bool ranges = kbytes * rb_rng + sbytes * ncr < kbytes * rb_all + sbytes;
-                if (const char* e = getenv("MOMA_K2_WIDE_PV")) ranges = e[0] == 'r';      // (diagnostic override: "ranges" / "all")
-                const int nj = ranges ? (int)rb_rng * ncr : (int)rb_all;
+                const int nj = ((p.Bpad / 32 + 7) / 8) * ncr;
                 int want = 256 / nj;
                 if (want < 1) want = 1;
                 cg = (p.nchunk + want - 1) / want;
+                if (cg > 8) cg = 8;
                 const int ngroups = (p.nchunk + cg - 1) / cg;
-#define MOMA_WIDE_PV(NS)                                                                                                      \
-                do {                                                                                                          \
-                    if (ranges) hipLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), 4 * 16384, st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16)); \
-                    else hipLaunchKernelGGL((infonce_wide_pv_kernel<NS, NS>), dim3(nj * ngroups), dim3(512), wide_pv_lds(NS), st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, xs, m_part, o_part, (long)(slab_bytes / 16)); \
-                } while (0)
+                wide_ref = r_part;
+#define MOMA_WIDE_PV(NS) hipLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), WIDE_PV2_LDS, st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, (const uint4*)xs, r_part, o_part, (long)(slab_bytes / 16))
                 if (nseg == 5) MOMA_WIDE_PV(5); else if (nseg == 6) MOMA_WIDE_PV(6); else if (nseg == 8) MOMA_WIDE_PV(8);
                 else if (nseg == 10) MOMA_WIDE_PV(10); else MOMA_WIDE_PV(12);
 #undef MOMA_WIDE_PV
@@ -1934,13 +1739,13 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 }
             }
         }
+        if (ev_end) (void)hipEventRecord(ev_end, st);
         float* rowstats = (float*)(((uintptr_t)((char*)xs + (size_t)p.Bpad * ntiles * KT * sizeof(float)) + 255) & ~(uintptr_t)255);
         hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
-                           m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, dq ? 1 : 0, rowstats);
+                           m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, dq ? 1 : 0, rowstats, wide_ref);
         if (dq)
             hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, d / 32), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
-                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, 2, rowstats);
-        if (ev_end) (void)hipEventRecord(ev_end, st);          // (the measurement hook spans every pass of the wide path)
+                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, 2, rowstats, wide_ref);
         return hipGetLastError();
     }
     const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
@@ -1962,7 +1767,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
-                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 0, (float*)nullptr);
+                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 0, (float*)nullptr, m_part);
     return hipGetLastError();
 }
 
