@@ -1411,12 +1411,11 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                const float* __restrict__ x_part,
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq,
-                                                               long slab_stride, int cg, int phase,
-                                                               float* __restrict__ rowstats,
+                                                               long slab_stride, int cg, int tpb,
                                                                const float* __restrict__ ref_part) {
     // ref_part: per (chunk, row) reference of the O partials when it is not m_part (wide rows: the integer references of pass 1)
-    // phase 0: everything in one launch (every column-tile block repeats the row statistics: 16x at d = 512, cheap);
-    // wide rows (40 column tiles at d = 1280): phase 1 = statistics + loss / lse / top-1, weights to `rowstats`; phase 2 = dq
+    // tpb: column tiles per block (grid.y = ceil(D/32 / tpb)).  Every block repeats the row statistics of its 8 rows: 16x at
+    // d = 512 with tpb = 1 (cheap); wide rows take 4 tiles per block (10x instead of 40x at d = 1280) in the same single launch.
     __shared__ __attribute__((aligned(16))) float wts[COMBINE_MAX_CHUNKS][8];
     __shared__ float accs[8][8][32];
     __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
@@ -1435,11 +1434,7 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
         return v;
     };
     const int nparts = (nchunk + cg - 1) / cg;                            // partial buffers: one per chunk (group)
-    float* rs = rowstats + (long)blockIdx.x * (nparts * 8 + 16);
-    if (phase == 2) {
-        for (int i = tid; i < nparts * 8; i += 256) (&wts[0][0])[i] = rs[i];
-        if (tid < 16) (&rowc[0][0])[tid] = rs[nparts * 8 + tid];
-    } else {
+    {
         const int rr = tid >> 5, l32 = tid & 31;
         const int b = row_of(rr);
         const bool live = b < B;
@@ -1519,19 +1514,14 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
             }
         }
     }
-    if (phase == 1) {
-        __syncthreads();
-        for (int i = tid; i < nparts * 8; i += 256) rs[i] = (&wts[0][0])[i];
-        if (tid < 16) rs[nparts * 8 + tid] = (&rowc[0][0])[tid];
-        return;
-    }
     if (dq == nullptr) return;
     __syncthreads();                                                     // wts[][], rowc[][] complete
     // dq: one 32-column tile of O per block; the 256 threads are 8 chunk-groups x 32 columns, every thread keeps up to 16 loads
     // of 16 B in flight (the kernel is one dependent sweep over 32 MB of partials: what matters is bytes in flight per CU)
     const int col = tid & 31, cgrp = tid >> 5;
     // wide queues (D > 512) keep one partial buffer per column slab of 512 (the last one narrower), `slab_stride` uint4 apart
-    const int c = blockIdx.y, n = col;
+    const int n = col;
+    for (int c = blockIdx.y * tpb; c < min((int)(blockIdx.y + 1) * tpb, D / 32); ++c) {
     const int sl = c >> 4, cl = c & 15;
     const int nct = min(16, D / 32 - 16 * sl);
     const long wb_stride = (long)nct * 2 * 64;                           // uint4 per wave block
@@ -1558,14 +1548,15 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < 16; ++u) fma8(v[u], ck + 8 * u);
     }
-    for (; ck + 56 < nparts; ck += 64) {                                 // (fewer partial buffers: 8 loads in flight)
-        uint4 v[8];
+    for (; ck < nparts; ck += 64) {                                      // the rest: up to 8 loads in flight, predicated
+        uint4 v[8];                                                      // (one at a time this tail was a chain of dependent
+#pragma unroll                                                           //  round trips: 43 chunk groups at d = 1280 -> 6 of them)
+        for (int u = 0; u < 8; ++u)
+            v[u] = (ck + 8 * u < nparts) ? src[(long)(ck + 8 * u) * chunk_stride] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(long)(ck + 8 * u) * chunk_stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) fma8(v[u], ck + 8 * u);
+        for (int u = 0; u < 8; ++u)
+            if (ck + 8 * u < nparts) fma8(v[u], ck + 8 * u);
     }
-    for (; ck < nparts; ck += 8) fma8(src[(long)ck * chunk_stride], ck);
 #pragma unroll
     for (int i = 0; i < 8; ++i) accs[cgrp][i][col] = acc[i];
     __syncthreads();
@@ -1579,6 +1570,8 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
             const long o = (long)b * D + c * 32 + col;
             dq[o] = (rowc[i][1] * k[o] + a * rowc[i][0]) * inv_T;
         }
+    }
+    __syncthreads();                                                     // accs[] is reused by the next column tile
     }
 }
 
@@ -1620,8 +1613,7 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const int ds = d > 512 ? 512 : d;                        // widest slab
     const int nslab = (d + 511) / 512;                       // one partial buffer per column slab
     size_t bytes = (size_t)nslab * rows * ds * 2 + 4 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
-    if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 512       // score scratch
-                          + (size_t)(p.Bpad / 8) * (p.nchunk * 8 + 16) * sizeof(float);           // row statistics of the combine
+    if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 512;      // score / P scratch
     return bytes;
 }
 
@@ -1740,12 +1732,13 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
             }
         }
         if (ev_end) (void)hipEventRecord(ev_end, st);
-        float* rowstats = (float*)(((uintptr_t)((char*)xs + (size_t)p.Bpad * ntiles * KT * sizeof(float)) + 255) & ~(uintptr_t)255);
-        hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad, o_part,
-                           m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, dq ? 1 : 0, rowstats, wide_ref);
-        if (dq)
-            hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, d / 32), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
-                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, 2, rowstats, wide_ref);
+        {
+            int tpb = 4;                                           // (measured at d = 1280: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call)
+            if (const char* e = getenv("MOMA_K2_COMBINE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;       // (diagnostic override)
+            const int nty = dq ? (d / 32 + tpb - 1) / tpb : 1;
+            hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, nty), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
+                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, tpb, wide_ref);
+        }
         return hipGetLastError();
     }
     const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
@@ -1767,7 +1760,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
-                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 0, (float*)nullptr, m_part);
+                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
     return hipGetLastError();
 }
 

@@ -1,5 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_step.py -x -q -m gpu -k "infonce or moco or loop or step" > gpurun_out/r2_tw15.log 2>&1; echo "pytest rc=$?"
-tail -3 gpurun_out/r2_tw15.log
-python bench.py --head None --no_cpu_baseline > gpurun_out/bench_r02_head_none.json 2> gpurun_out/bench_r02_head_none.err; tail -1 gpurun_out/bench_r02_head_none.json | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print(j['value'], j['ms_per_step'], r['frac'], r['ms_per_launch'], r['whole_call_ms'])"
+L=gpurun_out/r2_wide18.log
+timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce or moco" > gpurun_out/r2_tw18.log 2>&1; echo "pytest rc=$?" > $L
+tail -3 gpurun_out/r2_tw18.log >> $L
+for t in 1 2 4 8; do
+echo "tpb=$t" >> $L
+MOMA_K2_COMBINE_TPB=$t timeout -k 10 120 python scripts/bench_k2.py 256 1280 65536 bf16 bf16 30 >> $L 2>&1
+done
+grep -v amdgpu.ids $L | grep -v "dq=False"
