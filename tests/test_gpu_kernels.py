@@ -234,7 +234,7 @@ def test_infonce_wide_rows_large_logits_and_repeatable(ops, d):
 
 
 @pytest.mark.parametrize("grad", [True, False])
-@pytest.mark.parametrize("d", [256, 512])
+@pytest.mark.parametrize("d", [256, 512, 768, 1280])
 @pytest.mark.parametrize("scale", [30.0, 25.0, 10.0, 6.0])
 def test_infonce_flash_overflow_repass(ops, scale, d, grad):
     """A key far down the chunk beats the first tile's max by tens to hundreds of log2 units.  Beyond the fixed
@@ -243,13 +243,16 @@ def test_infonce_flash_overflow_repass(ops, scale, d, grad):
     units); below it (scale 10 / 6 -> ~96 / 58) the single pass must carry the range by itself.  Without a gradient the
     forward-only kernel runs, which moves its reference on the fly (online softmax, no O to rescale)."""
     rng = np.random.default_rng(7)
-    B, K, T = 40, 3000, 0.15
+    # (wide rows, d > 512: the score pass stores bf16 P against an integer reference fixed by the chunk's first tile and repeats
+    #  the chunk when a later tile overflows it -- K = 20000 gives chunks of 3 tiles, keys 1500 / 3031 sit in their second tiles)
+    B, K, T = 40, (3000 if d <= 512 else 20000), 0.15
+    k2 = 2999 if d <= 512 else 3031
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
     # rows 5 and 17 see a huge logit at keys 1500 / 2999 (late tiles of their chunks): s = |q|*30/T ~ 200 nats
     queue[1500] = scale * q[5] / np.linalg.norm(q[5])
-    queue[2999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
+    queue[k2] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
     tq = _t(q).requires_grad_(grad)
     tqueue = _t(queue, torch.bfloat16)
     qe = tqueue.float().cpu().numpy()
