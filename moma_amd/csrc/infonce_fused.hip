@@ -10,7 +10,7 @@
 //   WG    = 4 waves, ONE wave per SIMD with the whole 512-register file; wave w owns 32 query rows:
 //             Q fragments [32 x D] bf16 as the B operand of the score MFMA   (D/4  VGPRs, resident)
 //             O accumulator [32 x D] fp32                                    (D/2  AGPR/VGPRs, resident)
-//   tile  = 32 keys x D bf16, double-buffered in LDS, filled by LDS-DMA (global_load_lds_dwordx4; the
+//   tile  = 32 keys x D bf16 in a ring of 4 LDS slots, filled by LDS-DMA (global_load_lds_dwordx4; the
 //           bank swizzle is applied on the per-lane SOURCE address, the LDS image is lane-linear per piece).
 //   score : X[key, q] = K_tile . Q^T      v_mfma_f32_32x32x16_bf16, A = keys (ds_read_b128), B = Q (regs)
 //           -> the query sits on the lane, the 32 keys of the tile in the 16 registers x 2 lane halves,
@@ -20,10 +20,12 @@
 //           permuted k order key(s,h,j) = 16s + 8(j>>2) + 4h + (j&3).
 //   The softmax reference m of a query row is FIXED to the row max of its chunk's first tile + 32 (bf16 and fp32
 //   share the exponent range, so P may exceed 1 without losing precision) and O is not rescaled per tile; should a
-//   later tile exceed m by more than 2^96 the wave takes a rare in-kernel RESCUE branch: new reference for the
-//   overflowing rows, O and l of those rows rescaled once, the tile's scores recomputed against the new reference.
+//   later tile exceed m by more than 2^96 the WORKGROUP repeats its chunk with the true row maxima as references
+//   (rare, workgroup-uniform branch; tests force it).
 //   Each WG leaves (m, l, max, O) per query row; a combine kernel merges the chunks, adds the positive
 //   logit (exact fp32) and writes loss / lse / top-1 / dq.  Two launches per call after the Q pre-pack.
+//   Wide rows (d > 512): two passes over the queue -- infonce_wide_scores_kernel / infonce_wide_pv2_kernel below --
+//   or, for widths those do not take, column-slab passes of this body (MODE 1 / 2).
 //
 // LDS image of a key tile: D/128 segments of [32 keys][128 cols] with 256-B rows,
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
@@ -151,10 +153,9 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
 
 // The softmax reference m of a query row is FIXED to (row max of its chunk's first tile) + REF_MARGIN: bf16 and fp32
 //   share the 8-bit exponent, so P = 2^(x - m) may exceed 1 by many orders of magnitude without losing precision and O
-//   is not rescaled per tile.  A wave that meets a score more than 2^OVERFLOW_THR above a row's m takes the RESCUE branch
-//   (rare, wave-uniform): the overflowing rows get m' = that score + REF_MARGIN, their O rows and l are multiplied by
-//   2^(m - m') once, and the tile's scores are recomputed against m' (the P already formed from them is discarded before
-//   it enters O or l).  tests/test_gpu_kernels.py forces the branch (guide rule 26).
+//   is not rescaled per tile.  A wave that meets a score more than 2^OVERFLOW_THR above a row's m raises a word in LDS and
+//   the workgroup repeats its chunk with the true row maxima (recorded by the first pass) as references -- `run_pass` below.
+//   tests/test_gpu_kernels.py forces the branch (guide rule 26).
 // MODE 0: the one-pass kernel described above (d = D).
 // MODE 1 / 2: wide queues (d > 512) go through column SLABS of D <= 512 columns of the same key tiles, with the complete
 //   score tiles kept in a scratch `xs` in register order (xs[((row-wave * ntiles + tile) * 64 + lane) * 16 + r]):
@@ -872,8 +873,8 @@ __global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __res
 // the first 64 fragments (1024 columns) in the 256 AGPRs, the rest in VGPRs (MFMA A/B operands may be AGPRs).  A key tile
 // (32 keys x d, up to 96 KiB) does not fit a ring, so the LDS-DMA unit is a PHASE of PSEG segments (32 keys x PSEG*128 columns,
 // 3 phase buffers): x accumulates over the NSEG/PSEG phases of a tile; behind the tile's last phase the wave updates its
-// online (max, sum) per lane half and stores the complete fp32 scores in register order (the P.K slab passes read them).
-// Leaves per (chunk, row): m = true maximum, l = sum 2^(x - m), max = m -- the partial format of the one-pass kernel.
+// online (max, sum) per lane half and stores P~ = bf16(2^(x - r)) in A-operand order for the P.K pass (below: `sweep`).
+// Leaves per (chunk, row): m = true maximum, l = sum 2^(x - m), max = m -- the partial format of the one-pass kernel -- and r.
 template <int NSEG, int PSEG>
 __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4* __restrict__ qpack,
                                                                      const bf16_raw* __restrict__ queue, int B, int K, int nbt,
