@@ -7,10 +7,13 @@
 // for parallelism and few dependent memory round trips, not for operand reuse:
 //   * one workgroup = one head x 32 query rows; its 8 waves split the KEYS (tile t of 32 keys goes to wave t%8),
 //     so N=256, H=4 already gives 32 workgroups x 8 waves with ONE key tile per wave and each K/V element is used by exactly one wave of the
-//     group -- operands therefore go global -> registers directly (fp32 -> bf16 on the way), no LDS staging:
-//       K as the A operand: lane (key n, half h2) reads 8 consecutive floats of its key row per k-step (32 B),
-//       V as the B operand: lane (col n, half h2) reads 8 keys of column 32c + n per k-step -- every load
-//       instruction covers two full 128-B row segments.
+//     group:
+//       Q, K as B / A operands of the score product: lane (row n, half h2) reads 8 consecutive floats of its row per
+//       k-step (32 B), global -> registers directly (fp32 -> bf16 on the way);
+//       V as the B operand of the context product needs the keys along k, i.e. a TRANSPOSED fragment: the wave's V tile
+//       (32 keys x hd) is loaded in full rows (16 x 16 B per lane, coalesced), converted to bf16 and staged in the wave's own
+//       slice of LDS as the swizzled [32 keys][128 cols] image of K2 (infonce_fused.hip), then read column-wise with
+//       ds_read_b64_tr_b16 (round 1: 64 strided 4-byte loads per lane).  Rows past N and columns past hd are staged as zeros.
 //   * scores X[key, q] = K_tile . Q^T with v_mfma_f32_32x32x16_bf16: the query sits on the lane, the tile's 32
 //     keys in 16 registers x 2 lane halves -> row max / sum are in-register plus one cross-half wave shuffle.
 //   * each wave gets an (m, l) pair per query over its keys, merged across the waves through LDS into the row
@@ -74,35 +77,43 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
 
     bf16x8 qf[KS];                              // B operand: lane (q = n, h2), pre-scaled by hd^-1/2 * log2(e)
     bf16x8 kf[KS];                              // A operand: lane (key n, h2)
-    float vv[NCT][2][8];                        // B operand of the context product, fp32 as loaded
     load_row_frags(qf, qbase, ld, q0 + n, N, hd, h2, scale_log2);
+    // ---- V tile of this wave: global (full rows) -> registers -> bf16 -> LDS image -> transposed fragments
+    //   slot i of lane L: key row 4i + (L>>4), 16-B bf16 chunk L&15 (columns 8*(L&15) .. +8) = two float4 loads
+    float4 va[8][2];
     auto load_v = [&](int t) {
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    // the k index of k-step s enumerates the keys in the order the score registers hold them:
-                    // register 8s + j is key 16s + 8*(j>>2) + 4*h2 + (j&3)
-                    const int key = t * KT + 16 * s + 8 * (j >> 2) + 4 * h2 + (j & 3), col = 32 * c + n;
-                    vv[c][s][j] = vbase[(long)min(key, N - 1) * ld + min(col, hd - 1)];
-                }
+        for (int i = 0; i < 8; ++i) {
+            const int key = t * KT + 4 * i + (lane >> 4), col = 8 * (lane & 15);
+            // unconditional loads from clamped addresses (a guarded load is sunk under its guard: branch + full wait per load)
+            const float* p = vbase + (long)min(key, N - 1) * ld + min(col, hd - 8);
+            va[i][0] = *reinterpret_cast<const float4*>(p);
+            va[i][1] = *reinterpret_cast<const float4*>(p + 4);
+        }
     };
-    // loads stay unconditional from clamped addresses (a guarded load is sunk under its guard: branch + full wait
-    // per load); the pin keeps them so, the select zeroes what lies past N / hd
-    auto mask_v = [&](int t) {
+    char* s_v = reinterpret_cast<char*>(s_o) + wave * (32 * DP * 4);          // the wave's slice (its partial O goes there later)
+    const unsigned lds_v = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)s_v;
+    auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+    auto stage_v = [&](int t) {                  // rows past N / columns past hd become zeros
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = t * KT + 16 * s + 8 * (j >> 2) + 4 * h2 + (j & 3), col = 32 * c + n;
-                    asm volatile("" : "+v"(vv[c][s][j]));
-                    vv[c][s][j] = (key < N && col < hd) ? vv[c][s][j] : 0.f;
-                }
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + (lane >> 4), ch = lane & 15;
+            const unsigned keep = (t * KT + row < N && 8 * ch < hd) ? 0xffffffffu : 0u;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w = __builtin_bit_cast(u32x4, cvt8(va[i][0], va[i][1], 1.f));
+            w &= keep;                                                        // (loads unconditional from clamped addresses)
+            const unsigned addr = lds_v + row * 256 + ((ch ^ swz(row)) << 4);
+            asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(w) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // the wave's own writes, in order before its reads
     };
+    // transposed-read lane offsets of the image (as the P.K product of K2): 16-lane group -> 4 keys x 16 columns
+    unsigned b_off;
+    {
+        const int i16 = lane & 15, q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
+        const int e = (2 * g2 + (p >> 1)) ^ h2;
+        b_off = lds_v + (4 * h2 + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4);
+    }
     auto scores = [&](int t, f32x16& x) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = 0.f;
@@ -153,12 +164,35 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
             const bf16x8 pa = bf16x8{(__bf16)p[8 * s + 0], (__bf16)p[8 * s + 1], (__bf16)p[8 * s + 2],
                                      (__bf16)p[8 * s + 3], (__bf16)p[8 * s + 4], (__bf16)p[8 * s + 5],
                                      (__bf16)p[8 * s + 6], (__bf16)p[8 * s + 7]};
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            // the 8 transposed reads of a k-step and their wait are ONE statement with early-clobber outputs: an asm load's
+            // destination counts as written at the end of its statement, so with the wait in a later statement hipcc would be
+            // free to copy a destination register before the data has landed
+            static_assert(NCT == 4, "four column tiles per k-step");
+            s16x4 kb[NCT][2];
+            const unsigned a00 = b_off, a01 = a00 ^ 32u, a10 = b_off ^ 64u, a11 = a10 ^ 32u;
+            const unsigned a20 = b_off ^ 128u, a21 = a20 ^ 32u, a30 = b_off ^ 192u, a31 = a30 ^ 32u;
+            if (s == 0)
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:2048\n\t"
+                             "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11 offset:2048\n\t"
+                             "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13 offset:2048\n\t"
+                             "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(kb[0][0]), "=&v"(kb[0][1]), "=&v"(kb[1][0]), "=&v"(kb[1][1]), "=&v"(kb[2][0]), "=&v"(kb[2][1]),
+                               "=&v"(kb[3][0]), "=&v"(kb[3][1])
+                             : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31) : "memory");
+            else
+                asm volatile("ds_read_b64_tr_b16 %0, %8 offset:4096\n\tds_read_b64_tr_b16 %1, %9 offset:6144\n\t"
+                             "ds_read_b64_tr_b16 %2, %10 offset:4096\n\tds_read_b64_tr_b16 %3, %11 offset:6144\n\t"
+                             "ds_read_b64_tr_b16 %4, %12 offset:4096\n\tds_read_b64_tr_b16 %5, %13 offset:6144\n\t"
+                             "ds_read_b64_tr_b16 %6, %14 offset:4096\n\tds_read_b64_tr_b16 %7, %15 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(kb[0][0]), "=&v"(kb[0][1]), "=&v"(kb[1][0]), "=&v"(kb[1][1]), "=&v"(kb[2][0]), "=&v"(kb[2][1]),
+                               "=&v"(kb[3][0]), "=&v"(kb[3][1])
+                             : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31) : "memory");
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-                const bf16x8 vb = bf16x8{(__bf16)vv[c][s][0], (__bf16)vv[c][s][1], (__bf16)vv[c][s][2],
-                                         (__bf16)vv[c][s][3], (__bf16)vv[c][s][4], (__bf16)vv[c][s][5],
-                                         (__bf16)vv[c][s][6], (__bf16)vv[c][s][7]};
-                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, O[c], 0, 0, 0);
+                const s16x8 vb = __builtin_shufflevector(kb[c][0], kb[c][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, vb), O[c], 0, 0, 0);
             }
         }
     };
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
         const float lse2 = merge_lse(m, l);
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
-        mask_v(wave);
+        stage_v(wave);
         context(x);
         if (lse_out != nullptr && wave == 0 && h2 == 0 && q0 + n < N) lse_out[(long)head * N + q0 + n] = lse2;
     } else {
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void mha_core_fwd_kernel(const float* __re
             scores(t, x);
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
-            mask_v(t);
+            stage_v(t);
             context(x);
         }
         if (lse_out != nullptr && wave == 0 && h2 == 0 && q0 + n < N) lse_out[(long)head * N + q0 + n] = lse2;
