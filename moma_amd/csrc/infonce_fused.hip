@@ -63,6 +63,10 @@ extern "C" int moma_debug_read_stamps(unsigned* host) {
 #define K2_STAMP(neg, pos) do { } while (0)
 #endif
 
+#ifndef MOMA_K2_WPV_SD
+#define MOMA_K2_WPV_SD 3        // wide P.K pass: key tiles (and their P) requested ahead; ring of SD + 1 slots of 16 KiB
+#endif
+
 namespace moma {
 namespace {
 
@@ -1126,7 +1130,7 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                                                                   uint4* __restrict__ o_part, long slab_stride) {
     constexpr int NCR = (NSEG + 1) / 2;             // column ranges of the row
     constexpr int SLOT = 2 * 8192;                  // 32 keys x 256 columns bf16
-    constexpr int NB = 4, SD = 3;                   // ring slots; tiles requested ahead (scores: 16 registers per tile)
+    constexpr int SD = MOMA_K2_WPV_SD, NB = SD + 1;   // tiles requested ahead (P: 8 registers per tile) and ring slots
     constexpr int OPT = 4;                          // vector-memory operations per wave and tile: 2 loads of P + 2 pieces
     constexpr int CGMAX = 8;                        // chunks per group (the launcher keeps cg <= CGMAX)
     constexpr int PF = 2;                           // column tiles of transposed reads in flight
@@ -1196,10 +1200,14 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
         switch (j) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPT) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPT) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * OPT) : "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * OPT) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * OPT) : "memory"); break;
         }
     };
-    static_assert(SD == 3, "wait_younger_tiles covers SD - 1 = 2 younger tiles");
+    static_assert(SD >= 2 && SD <= 7, "wait_younger_tiles covers up to 6 younger tiles");
 #pragma unroll
     for (int j = 0; j < SD; ++j)
         if (t0 + j < t1) {
@@ -1598,7 +1606,7 @@ FlashPlan plan(int B, int K) {
 
 }  // namespace
 
-constexpr int WIDE_PV2_LDS = 4 * 16384 + 8 * 8 * 64 * 4;        // ring of 4 x (32 keys x 256 columns) + the scale-factor table
+constexpr int WIDE_PV2_LDS = (MOMA_K2_WPV_SD + 1) * 16384 + 8 * 8 * 64 * 4;     // ring of (32 keys x 256 columns) slots + the scale-factor table
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
 static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
 
