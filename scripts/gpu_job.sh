@@ -1,10 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-L=gpurun_out/r2_wide20.log
-: > $L
-for v in "" sd5 sd7 "" sd5 sd7; do
-if [ -z "$v" ]; then echo "sd3" >> $L; timeout -k 10 120 python scripts/bench_k2.py 256 1280 65536 bf16 bf16 30 >> $L 2>&1
-else echo $v >> $L; MOMA_HIP_LIB=moma_amd/lib/variants/lib_$v.so timeout -k 10 120 python scripts/bench_k2.py 256 1280 65536 bf16 bf16 30 >> $L 2>&1; fi
-done
-MOMA_HIP_LIB=moma_amd/lib/variants/lib_sd5.so timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce" > gpurun_out/r2_tw20.log 2>&1; echo "pytest(sd5) rc=$?" >> $L
-grep -v amdgpu.ids $L | grep -v "dq=False"
+timeout -k 10 1100 python -m pytest tests/ -x -q -m gpu > gpurun_out/r2_full4.log 2>&1; echo "pytest rc=$?"
+tail -3 gpurun_out/r2_full4.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+bash scripts/collect_profiles.sh r02 > gpurun_out/collect_r02.log 2>&1
+grep -c wrote gpurun_out/collect_r02.log
+python bench.py > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -1 gpurun_out/bench_r02.json | cut -c1-160
+python bench.py --head None --no_cpu_baseline > gpurun_out/bench_r02_head_none.json 2> gpurun_out/bench_r02_head_none.err; tail -1 gpurun_out/bench_r02_head_none.json | cut -c1-160
