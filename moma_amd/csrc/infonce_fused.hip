@@ -559,7 +559,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // (the pipelined loop puts the NEXT tile's softmax there).  prefetched_tag: the first PF column tiles were already requested
     // by the preceding score product (score_dispatch_pv).
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    auto pv = [&](auto prefetched_tag, const char* buf, const bf16x8 (&pa)[2], auto&& between) __attribute__((always_inline)) {
+    auto pv = [&](auto prefetched_tag, const char* buf, const bf16x8 (&pa)[2], auto&& between_a, auto&& between) __attribute__((always_inline)) {
         if constexpr (WITH_DQ) {
             if constexpr (!decltype(prefetched_tag)::value) {
                 pv_setup(buf);
@@ -589,6 +589,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 asm volatile("" ::"v"(k0), "v"(pa[0]));
 #endif
                 if (c + PF < NCT) issue_lo(c + PF);               // LDS requests in the first MFMA's shadow
+                between_a(c);                                      // (the gap behind the first MFMA carries no wait: room for 12 cycles)
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef MOMA_K2_ABL_NO_PV_MFMA
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
@@ -709,17 +710,29 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // SM_SHIFT column tiles into P.K: the score MFMAs were issued without trailing wait states, and no VALU may read
             // their accumulator before >= 4 further MFMAs have gone by.
             constexpr int SM_SHIFT = 2;
-            auto sm_step = [&](int j) __attribute__((always_inline)) {
+            // The step is split over the two gaps of a column tile: maximum + exponential (12 issue cycles) behind the first MFMA,
+            // whose gap carries only the two reads; the sum behind the second, whose gap also carries the wait (a whole step
+            // there made that gap 36 cycles against the MFMA's 32, while the first one idled).
+            auto sm_step_a = [&](int j) __attribute__((always_inline)) {
 #ifndef MOMA_K2_ABL_NO_SOFTMAX
                 asm volatile("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(xb[j]));       // (pinned here: left to hipcc the maxima sink
                 asm volatile("v_exp_f32 %0, %0" : "+v"(xb[j]));                       //  behind the barrier and every x is copied first)
+#endif
+            };
+            auto sm_step_b = [&](int j) __attribute__((always_inline)) {
+#ifndef MOMA_K2_ABL_NO_SOFTMAX
                 if (j >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[j - 1]));
 #endif
             };
-            pv(std::true_type{}, slot(t), pa, [&](int c) __attribute__((always_inline)) {
-                if (c == SM_SHIFT) mask_tail(xb, t + 1);
-                if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step(c - SM_SHIFT);
-            });
+            auto sm_step = [&](int j) __attribute__((always_inline)) { sm_step_a(j); sm_step_b(j); };
+            pv(std::true_type{}, slot(t), pa,
+               [&](int c) __attribute__((always_inline)) {
+                   if (c == SM_SHIFT) mask_tail(xb, t + 1);
+                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_a(c - SM_SHIFT);
+               },
+               [&](int c) __attribute__((always_inline)) {
+                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_b(c - SM_SHIFT);
+               });
 #pragma unroll
             for (int j = (NCT > SM_SHIFT ? NCT - SM_SHIFT : 0); j < 16; ++j) {
                 if (NCT <= SM_SHIFT && j == 0) mask_tail(xb, t + 1);
@@ -759,7 +772,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
         {
             uint4* dst = opart_dst();
-            pv(std::false_type{}, slot(t1 - 1), pa, [&](int c) __attribute__((always_inline)) {
+            pv(std::false_type{}, slot(t1 - 1), pa, [&](int) __attribute__((always_inline)) {}, [&](int c) __attribute__((always_inline)) {
                 if (c >= 1) store_tile(dst, c - 1);
             });
             store_tile(dst, NCT - 1);
@@ -794,7 +807,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                     for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - m_ref);      // m_ref = the row's lse (log2)
                     bf16x8 pa[2];
                     pack(x, pa);
-                    pv(std::false_type{}, slot(t), pa, [&](int) __attribute__((always_inline)) {});
+                    pv(std::false_type{}, slot(t), pa, [&](int) __attribute__((always_inline)) {}, [&](int) __attribute__((always_inline)) {});
                 }
             } else {
                 f32x16 x;

@@ -1,9 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests/ -x -q -m gpu > gpurun_out/r2_full4.log 2>&1; echo "pytest rc=$?"
-tail -3 gpurun_out/r2_full4.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash scripts/collect_profiles.sh r02 > gpurun_out/collect_r02.log 2>&1
-grep -c wrote gpurun_out/collect_r02.log
-python bench.py > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -1 gpurun_out/bench_r02.json | cut -c1-160
-python bench.py --head None --no_cpu_baseline > gpurun_out/bench_r02_head_none.json 2> gpurun_out/bench_r02_head_none.err; tail -1 gpurun_out/bench_r02_head_none.json | cut -c1-160
+L=gpurun_out/r2_abl20.log
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce or moco" > gpurun_out/r2_t20.log 2>&1; echo "pytest rc=$?" > $L
+for i in 1 2; do
+python scripts/ablate_k2.py >> $L 2>&1
+MOMA_HIP_LIB=moma_amd/lib/variants/lib_head.so python scripts/ablate_k2.py >> $L 2>&1
+done
+grep -v amdgpu.ids $L | grep "rc=\|dq=True"
