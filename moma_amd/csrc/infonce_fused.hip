@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void infonce_qpack_kernel(const float* __restr
 // MODE 1 / 2: wide queues (d > 512) go through column SLABS of D <= 512 columns of the same key tiles, with the complete
 //   score tiles kept in a scratch `xs` in register order (xs[((row-wave * ntiles + tile) * 64 + lane) * 16 + r]):
 //   MODE 1 adds this slab's partial scores to the scratch (first slab: stores), nothing else;
-//   MODE 2 reads the finished scores, forms normalised P = 2^(x - lse2) and accumulates this slab's columns of O.
+//   MODE 2 reads the finished scores, forms P = 2^(x - chunk max) and accumulates this slab's columns of O (un-normalised:
+//   the combine kernel weighs the chunks, as for the one-pass kernel).
 //   `queue` then points at the slab's first column and `slab` carries the row pitch and the first-slab flag.
 struct SlabArgs {
     float* xs;
-    const float* lse;     // [B] natural-log lse of the complete logits (MODE 2, normalised P) -- or
     const float* mref;    // [nchunk][Bpad] log2 reference per (chunk, row) (MODE 2, P = 2^(x - mref): the combine kernel weighs)
     unsigned pitch;       // bytes between queue rows
     int first;            // MODE 1: this is the first slab (store instead of accumulate)
@@ -224,7 +224,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 
     float m_ref = NEG_BIG;
     if constexpr (MODE == 2)
-        m_ref = slab.mref ? slab.mref[prow + n] : slab.lse[min(bt * QROWS_WG + wave * 32 + n, B - 1)] * 1.4426950408889634f;
+        m_ref = slab.mref[prow + n];
     // MODE 2: the finished scores of tile t are loaded one tile ahead by inline asm (counted by hand like the Q loads: at the
     // first use of an ordinary load hipcc drains vmcnt to 0, the whole tile ring included, and the load's own latency -- a
     // round trip to the scratch in HBM / Infinity Cache -- was exposed once per tile)
@@ -1707,7 +1707,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
             if (ev_begin) (void)hipEventRecord(ev_begin, st);      // (slab passes: a pre-pack per slab sits between the passes)
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
                 const int D = slab_width(col0);
-                const SlabArgs sa{xs, nullptr, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
+                const SlabArgs sa{xs, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
                 const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
 #define MOMA_SLAB_SCORES(DD)                                                                                             \
                 do {                                                                                                         \
@@ -1744,7 +1744,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 int sl = 0;
                 for (int col0 = 0; col0 < d; col0 += slab_width(col0), ++sl) {
                     const int D = slab_width(col0);
-                    const SlabArgs sa{xs, nullptr, m_part, (unsigned)(d * 2), 0};
+                    const SlabArgs sa{xs, m_part, (unsigned)(d * 2), 0};
                     const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
                     uint4* op = (uint4*)((char*)o_part + (size_t)sl * slab_bytes);
 #define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, op, sa)

@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-L=gpurun_out/r2_abl20.log
-timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce or moco" > gpurun_out/r2_t20.log 2>&1; echo "pytest rc=$?" > $L
-for i in 1 2; do
-python scripts/ablate_k2.py >> $L 2>&1
-MOMA_HIP_LIB=moma_amd/lib/variants/lib_head.so python scripts/ablate_k2.py >> $L 2>&1
-done
-grep -v amdgpu.ids $L | grep "rc=\|dq=True"
+timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce or moco" > gpurun_out/r2_t21.log 2>&1; echo "pytest rc=$?"
+tail -2 gpurun_out/r2_t21.log
