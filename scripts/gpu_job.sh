@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "infonce or moco" > gpurun_out/r2_t21.log 2>&1; echo "pytest rc=$?"
-tail -2 gpurun_out/r2_t21.log
+timeout -k 10 1000 python scripts/sweep_k1.py 150 3 > gpurun_out/sweep_k1.log 2>&1; echo "rc=$?"
+grep -v amdgpu.ids gpurun_out/sweep_k1.log | grep -v "^ok" | tail -12
