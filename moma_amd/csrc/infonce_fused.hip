@@ -31,6 +31,7 @@
 //   off(seg,row,ch) = seg*8192 + row*256 + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))      ch = 16-B chunk 0..15
 // which is conflict-free for both the row reads (ds_read_b128) and the transposed reads.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -1692,11 +1693,12 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         // (the measurement events span the passes over the queue -- scores and P.K -- like the one-pass path, where they span the
         //  flash kernel: the Q pre-pack in front and the combine behind are outside in both)
         const int nseg = d / 128;
+        bool ev_on_dispatch = false;                           // the two-pass kernels carry the measurement events on their dispatches
 #define MOMA_WIDE_SCORES(NS, PS, DD)                                                                                          \
         do {                                                                                                                  \
             hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
-            if (ev_begin) (void)hipEventRecord(ev_begin, st);                                                                 \
-            hipLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192 + 16, st, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, (uint4*)xs, m_part, l_part, x_part, r_part); \
+            hipExtLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192 + 16, st, ev_begin, dq ? (hipEvent_t) nullptr : ev_end, 0, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, (uint4*)xs, m_part, l_part, x_part, r_part); \
+            ev_on_dispatch = true;                                                                                            \
         } while (0)
         if (nseg == 5) MOMA_WIDE_SCORES(5, 5, 640);
         else if (nseg == 6) MOMA_WIDE_SCORES(6, 6, 768);
@@ -1736,7 +1738,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 if (cg > 8) cg = 8;
                 const int ngroups = (p.nchunk + cg - 1) / cg;
                 wide_ref = r_part;
-#define MOMA_WIDE_PV(NS) hipLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), WIDE_PV2_LDS, st, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, (const uint4*)xs, r_part, o_part, (long)(slab_bytes / 16))
+#define MOMA_WIDE_PV(NS) hipExtLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), WIDE_PV2_LDS, st, (hipEvent_t) nullptr, ev_end, 0, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, (const uint4*)xs, r_part, o_part, (long)(slab_bytes / 16))
                 if (nseg == 5) MOMA_WIDE_PV(5); else if (nseg == 6) MOMA_WIDE_PV(6); else if (nseg == 8) MOMA_WIDE_PV(8);
                 else if (nseg == 10) MOMA_WIDE_PV(10); else MOMA_WIDE_PV(12);
 #undef MOMA_WIDE_PV
@@ -1753,7 +1755,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 }
             }
         }
-        if (ev_end) (void)hipEventRecord(ev_end, st);
+        if (ev_end && !ev_on_dispatch) (void)hipEventRecord(ev_end, st);      // (slab passes: recorded behind the last pass)
         {
             int tpb = 4;                                           // (measured at d = 1280: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call)
             if (const char* e = getenv("MOMA_K2_COMBINE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;       // (diagnostic override)
@@ -1768,10 +1770,10 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #define MOMA_FLASH_LAUNCH(DD)                                                                             \
     do {                                                                                                  \
         hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
-        if (ev_begin) (void)hipEventRecord(ev_begin, st);                                                 \
-        if (dq) hipLaunchKernelGGL((infonce_flash_kernel<DD, true>), grid, block, lds, st, MOMA_FLASH_ARGS);  \
-        else hipLaunchKernelGGL((infonce_flash_kernel<DD, false>), grid, block, lds, st, MOMA_FLASH_ARGS);    \
-        if (ev_end) (void)hipEventRecord(ev_end, st);                                                     \
+        /* measurement events ride on the dispatch itself (kernel begin / end timestamps, what rocprofv3 reports): events   */ \
+        /* recorded around the launch add the latency of two event packets, ~3 us on a 36 us kernel                        */ \
+        if (dq) hipExtLaunchKernelGGL((infonce_flash_kernel<DD, true>), grid, block, lds, st, ev_begin, ev_end, 0, MOMA_FLASH_ARGS);  \
+        else hipExtLaunchKernelGGL((infonce_flash_kernel<DD, false>), grid, block, lds, st, ev_begin, ev_end, 0, MOMA_FLASH_ARGS);    \
     } while (0)
     if (d == 512) MOMA_FLASH_LAUNCH(512);
     else if (d == 384) MOMA_FLASH_LAUNCH(384);
