@@ -211,6 +211,10 @@ __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r32 = lane & 31, kh = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    // batched products (the per-head products of the staged attention path): one batch entry per blockIdx.z
+    g.A += (long)blockIdx.z * g.strideA;
+    g.B = reinterpret_cast<const float*>(g.B) + (long)blockIdx.z * g.strideB;
+    g.C += (long)blockIdx.z * g.strideC;
     const int steps = g.K / 16;                                     // k-steps of 16 (K % 16 == 0 by dispatch)
     const int base = steps / 4, rem = steps % 4;
     const int sb = wave * base + min(wave, rem), ns = base + (wave < rem ? 1 : 0);
@@ -285,11 +289,13 @@ __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
 }
 
 bool linear_ksplit_ok(const GemmArgs& a) {
-    if (a.prec != MOMA_PREC_BF16 || a.b_dtype != MOMA_DT_F32 || a.batch != 1 || a.splitk != 1 || a.atomic) return false;
+    if (a.prec != MOMA_PREC_BF16 || a.b_dtype != MOMA_DT_F32 || a.batch < 1 || a.batch > 65535 || a.splitk != 1 || a.atomic) return false;
     if (a.K < 64 || a.K % 16 != 0) return false;
-    if (!a.transA && !(((uintptr_t)a.A % 16) == 0 && a.lda % 4 == 0)) return false;
-    if (!a.transB && !(((uintptr_t)a.B % 16) == 0 && a.ldb % 4 == 0)) return false;
-    const long tiles = (long)((a.N + 31) / 32) * ((a.M + 31) / 32);
+    const bool batched = a.batch > 1;
+    if (batched && (a.bias != nullptr || a.colsum_a != nullptr)) return false;
+    if (!a.transA && !(((uintptr_t)a.A % 16) == 0 && a.lda % 4 == 0 && (!batched || a.strideA % 4 == 0))) return false;
+    if (!a.transB && !(((uintptr_t)a.B % 16) == 0 && a.ldb % 4 == 0 && (!batched || a.strideB % 4 == 0))) return false;
+    const long tiles = (long)((a.N + 31) / 32) * ((a.M + 31) / 32) * a.batch;
     return tiles <= 1024;                                           // past that the 64 x 64 tiles re-read less from L2
 }
 }  // namespace
@@ -340,7 +346,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     // every output element stays ONE fixed-order sum, so the results are bitwise reproducible.  (A caller that wants a K
     // split over workgroups asks for it explicitly with splitk / atomic: only the materialised-logits gradient does.)
     if (linear_ksplit_ok(a)) {
-        const dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+        const dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, a.batch);
         if (a.transA && a.transB) hipLaunchKernelGGL((linear_ksplit_kernel<true, true>), grid, dim3(256), 0, s, a);
         else if (a.transA) hipLaunchKernelGGL((linear_ksplit_kernel<true, false>), grid, dim3(256), 0, s, a);
         else if (a.transB) hipLaunchKernelGGL((linear_ksplit_kernel<false, true>), grid, dim3(256), 0, s, a);
