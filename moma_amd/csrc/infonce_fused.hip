@@ -710,7 +710,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // sum lags one step (no instruction reads a transcendental result right behind its v_exp_f32).  The steps start
             // SM_SHIFT column tiles into P.K: the score MFMAs were issued without trailing wait states, and no VALU may read
             // their accumulator before >= 4 further MFMAs have gone by.
-            constexpr int SM_SHIFT = 2;
+#ifndef MOMA_K2_SM_SHIFT
+#define MOMA_K2_SM_SHIFT 2
+#endif
+            constexpr int SM_SHIFT = MOMA_K2_SM_SHIFT;
             // The step is split over the two gaps of a column tile: maximum + exponential (12 issue cycles) behind the first MFMA,
             // whose gap carries only the two reads; the sum behind the second, whose gap also carries the wait (a whole step
             // there made that gap 36 cycles against the MFMA's 32, while the first one idled).
