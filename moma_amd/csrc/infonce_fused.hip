@@ -618,7 +618,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 v.y = (unsigned)f32_to_bf16(O[c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[c][8 * g + 3]) << 16);
                 v.z = (unsigned)f32_to_bf16(O[c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[c][8 * g + 5]) << 16);
                 v.w = (unsigned)f32_to_bf16(O[c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g + 7]) << 16);
-                dst[(c * 2 + g) * 64] = v;
+                dst[(c * 2 + g) * 64] = v;     // (non-temporal stores: same kernel time, +3 us on the combine that reads them back)
             }
 #else
             asm volatile("" ::"v"(O[c]));
