@@ -204,6 +204,9 @@ namespace {
 // an operand stored K-contiguous, 8 x 4 B (32 consecutive rows per k: coalesced) for one stored K-major -- so the whole
 // kernel is ONE load round trip, 8 MFMAs per wave, and a fixed-order sum of the four partial tiles through LDS
 // (bitwise reproducible, no atomics).  No LDS staging, no transposition pass for the gradient products.
+// (Tried: the K-contiguous panels loaded in full rows, converted and staged through 16 KiB of LDS per wave, fragments read back
+//  with ds_read_b128 -- 8 cache lines per load instead of 64.  Slower, 15.0 vs 12.9 us on the qkv linear: the 64 KiB of LDS
+//  halve the workgroups per CU and the extra LDS round trip outweighs the cheaper loads.)
 template <bool TRA, bool TRB>
 __global__ __launch_bounds__(256) void linear_ksplit_kernel(GemmArgs g) {
     __shared__ float red[4][16][64];
