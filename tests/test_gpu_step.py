@@ -306,3 +306,63 @@ def test_loop_cross_attention_paths_match_step_oracle(mem, attn):
     np.testing.assert_allclose(losses, [r[0] for r in ref], rtol=0, atol=2e-3)        # (backbone: MIOpen vs CPU convolutions)
     np.testing.assert_allclose(kds, [r[2] for r in ref], rtol=0, atol=2e-3)
     np.testing.assert_allclose(contrast.memory.cpu().numpy(), ocontrast.memory.numpy(), rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("d,K", [(768, 8192), (1280, 16384)])
+def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
+    """Wide feature dims (the regime of the reference CLI's default `--head None`: EfficientNet-B0 -> d = 1280) at LOOP level under
+    the bf16 policy: the two-pass wide-row K2 (infonce_wide_scores_kernel + infonce_wide_pv2_kernel, bf16 queue), the staged K1
+    path with its batched K-split products (head dim 192 / 320 > 128), K3, K4; teacher side on the second stream.  3 steps of
+    train_distill_moma against the CPU step oracle (fp32; its pieces are pinned to the reference by G1-G5).  Tolerances as in
+    the big-queue test: first step 1e-3 relative (the kernels' own error), later steps 5e-3 (bf16 gradient rounding through SGD)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import copy
+    from oracle.step_oracle import OracleCMO, OracleMoCo, StepOracle
+    from moma_amd.backbones.resnet_cifar import resnet8
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.distiller_zoo import DistillKL
+    torch.backends.cudnn.benchmark = False
+    B, lr = 8, 0.002
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.999,
+                             cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
+                             batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
+                             moma_fused=True, trace=[], overlap_teacher=True, graph_teacher=False, local_rank=0, node_rank=0,
+                             ngpus_per_node=1)
+    torch.manual_seed(4321 + d)
+    ms, mt = resnet8(num_classes=10), resnet8(num_classes=10)
+    contrast = build_mem(opt)
+    kd = CMO(opt)
+    oms, omt = copy.deepcopy(ms), copy.deepcopy(mt)
+    ocmo = OracleCMO("mlp", 64, 64, d, attn="self")
+    ocmo.load_state_dict(kd.state_dict())
+    ocontrast = OracleMoCo(d, K, 0.15)
+    ocontrast.memory.copy_(contrast.memory.float())              # (the oracle sees the bf16-rounded queue the kernels read)
+    run = StepOracle(oms, omt, ocmo, ocontrast, head="mlp", lr=lr, attn="self")
+    dev = torch.device("cuda", 0)
+    ms, mt, contrast, kd = ms.to(dev), mt.to(dev), contrast.to(dev), kd.to(dev)
+    trainer = ContrastTrainer(opt)
+    trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+    optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
+    g = torch.Generator().manual_seed(19)
+    loader = [(torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)) for _ in range(3)]
+    torch.manual_seed(77)
+    train_distill_moma(1, loader, nn.ModuleList([ms, mt]), crits, trainer, contrast, optimizer, opt)
+    torch.manual_seed(77)
+    run.start_epoch()
+    ref = [run.step(x, y) for x, y in loader]
+    kds = np.array([float(t[2]) for t in opt.trace])
+    losses = np.array([float(t[0]) for t in opt.trace])
+    ref_kd, ref_loss = np.array([r[2] for r in ref]), np.array([r[0] for r in ref])
+    print("loss_kd |err|:", np.abs(kds - ref_kd).round(5), " total |err|:", np.abs(losses - ref_loss).round(5))
+    assert [t[1] for t in opt.trace] == [(i + 1) * B % K for i in range(3)] and ocontrast.index == contrast.index
+    assert abs(kds[0] - ref_kd[0]) < 1e-3 * abs(ref_kd[0])
+    np.testing.assert_allclose(kds, ref_kd, rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(losses, ref_loss, rtol=5e-3, atol=5e-3)
+    rows = contrast.memory[:3 * B].float().cpu().numpy()
+    ref_rows = ocontrast.memory[:3 * B].numpy()
+    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
