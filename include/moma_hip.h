@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MOMA_ABI_VERSION 2
+#define MOMA_ABI_VERSION 3
 
 enum { MOMA_PREC_F32 = 0, MOMA_PREC_BF16 = 1 };
 enum { MOMA_DT_F32 = 0, MOMA_DT_BF16 = 1 };
@@ -125,33 +125,84 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
                           float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
                           void* workspace, size_t workspace_bytes, int qdtype, int prec,
                           moma_stream_t stream, void* ev_begin, void* ev_end);
+/* Same, with the query ALSO handed over pre-packed: q_packed (nullable) holds q * inv_T * log2(e) rounded to bf16 in the
+ * MFMA-operand order the one pass over the queue loads it in,
+ *     unit[((row / 32) * (d / 16) + col / 16) * 64 + ((col / 8) & 1) * 32 + row % 32] = 8 bf16 = columns 8 * (col / 8) .. + 7 of row,
+ * 16 bytes per unit, rows padded to a multiple of 128 with zeros: moma_infonce_qpack_bytes(B, d) bytes (0 = this width takes
+ * no pre-packed query: d must be 128 / 256 / 384 / 512).  The producer of q writes it -- moma_mha_fwd_fast does when asked
+ * (moma_mha_module_t.qpack) -- and the call then runs no pre-pack launch.  q itself (fp32) is still read for the exact positive
+ * logit.  The results are bit-identical to moma_infonce_fused_ex on the same q. */
+size_t moma_infonce_qpack_bytes(int B, int d);
+int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
+                         float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
+                         void* workspace, size_t workspace_bytes, int qdtype, int prec,
+                         moma_stream_t stream, void* ev_begin, void* ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * K1  batch-token multi-head attention -- replaces Attention.forward
  *     (MoMA/criterion_moco_att.py:153-167) and its autograd backward.
  *     x [N,d] -> qkv = x Wqkv^T + bqkv -> per head softmax(q k^T * hd^-1/2) v -> y = a Wproj^T + bproj.
- *     State the forward keeps for the backward (caller-owned): qkv [N,3d], attn_out [N,d] and ONE of
- *       MOMA_MHA_SAVE_LSE   lse [H,N]     row log-sum-exp of the scaled scores in log2 units -- the fused per-head core
- *                                         (MOMA_PREC_BF16, head dim a multiple of 16 and <= 128: scores, softmax and context
- *                                         of :159-163 in ONE launch, flash-style: the backward recomputes P per tile, so no
- *                                         [H,N,N] array exists at any N; attn = 'all' runs over N = 2B + K tokens);
- *       MOMA_MHA_SAVE_PROBS probs [H,N,N] the staged path (exact-fp32 policy, other head dims): the reference's op chain.
- *     moma_mha_saved_state() says which; the other pointer may be NULL (both may be NULL for a forward without backward
- *     on the fused path, e.g. the no-grad key / queue modules).
- *     bwd writes dx [N,d], dw_qkv [3d,d], db_qkv [3d], dw_proj [d,d], db_proj [d]; any of the five may
- *     be NULL to skip it.  bwd workspace: moma_mha_bwd_workspace_bytes().  No atomics anywhere: results are bitwise
- *     reproducible run to run.
+ *
+ *   Two families of entry points; moma_mha_saved_state() says which one a configuration takes:
+ *
+ *   MOMA_MHA_SAVE_LSE  ->  the FAST path (moma_mha_pack_weights / moma_mha_fwd_fast / moma_mha_bwd_fast): MOMA_PREC_BF16 with a
+ *     head dim that is a multiple of 16 and <= 128 (every `--head mlp` configuration).  Flash-style: the forward keeps the
+ *     row log-sum-exp lse [H,N] (log2 units, scale included) and the backward recomputes P per tile, so no [H,N,N] array
+ *     exists at any N (attn = 'all' runs over N = 2B + K tokens).  Everything a launch reads more than once is bf16:
+ *       pack    caller-owned, moma_mha_pack_bytes(d) bytes: [Wqkv | Wproj | Wqkv^T | Wproj^T] as bf16, written by
+ *               moma_mha_pack_weights (one launch; with_transposed = 0 fills only the first half -- enough for a forward);
+ *               the caller refreshes it when the fp32 weights change (after optimizer.step());
+ *       qkv16   [N,3d] bf16, the Q third pre-scaled by hd^-1/2 * log2(e);  attn16 [N,d] bf16  (both saved for the backward,
+ *               together with x, lse and the pack);
+ *     moma_mha_fwd_fast runs n_modules <= 4 modules of equal (N, d, H) in the SAME three launches (qkv linear, per-head core,
+ *     proj linear: blockIdx selects the module) -- the loop's atts_k and atts_queue (helper/loops_moma.py:327-329) run as one
+ *     group.  A module with qpack != NULL also gets y * qpack_scale in the packed bf16 MFMA-operand layout that
+ *     moma_infonce_fused_q consumes (so K2 needs no pre-pack launch; the buffer has moma_infonce_qpack_bytes(N, d) bytes and
+ *     its pad rows must be zero -- zero it once).
+ *     moma_mha_bwd_fast: 3 launches -- {dA = dy Wproj with the row dots D, dWproj, dbproj} -> core (dQ | dK | dV) ->
+ *     {dWqkv, dbqkv, dx}.  dx / (dw_qkv, db_qkv) / (dw_proj, db_proj) may be NULL to skip them; a bias gradient is only
+ *     produced together with its weight gradient.  workspace: moma_mha_bwd_fast_workspace_bytes().
+ *
+ *   MOMA_MHA_SAVE_PROBS  ->  the STAGED path (moma_mha_fwd / moma_mha_bwd): the reference's op chain on one generic MFMA GEMM
+ *     plus row softmax kernels -- exact fp32 under MOMA_PREC_F32 (f32-input MFMA), any N, d, H; keeps qkv [N,3d],
+ *     attn_out [N,d] and probs [H,N,N] in fp32 for the backward.
+ *     bwd writes dx [N,d], dw_qkv [3d,d], db_qkv [3d], dw_proj [d,d], db_proj [d]; any of the five may be NULL to skip it.
+ *     bwd workspace: moma_mha_bwd_workspace_bytes().
+ *   No atomics anywhere: results are bitwise reproducible run to run.  One device per process (kernel attributes are set once).
  * ------------------------------------------------------------------------------------------- */
 enum { MOMA_MHA_SAVE_PROBS = 0, MOMA_MHA_SAVE_LSE = 1 };
 int moma_mha_saved_state(int N, int d, int H, int prec);
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj,
-                 const float* b_proj, float* y, float* qkv, float* probs, float* lse, float* attn_out,
+                 const float* b_proj, float* y, float* qkv, float* probs, float* attn_out,
                  int N, int d, int H, int prec, moma_stream_t stream);
 size_t moma_mha_bwd_workspace_bytes(int N, int d, int H, int prec);
 int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv,
-                 const float* probs, const float* lse, const float* attn_out, const float* dy, float* dx,
+                 const float* probs, const float* attn_out, const float* dy, float* dx,
                  float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj, void* workspace,
                  size_t workspace_bytes, int N, int d, int H, int prec, moma_stream_t stream);
+
+typedef struct moma_mha_module {
+    const void* x;        /* [N,d] input, fp32 or bf16 (x_dtype)                           */
+    const void* pack;     /* bf16 weight pack (moma_mha_pack_weights)                      */
+    const float* b_qkv;   /* [3d] or NULL                                                  */
+    const float* b_proj;  /* [d]                                                           */
+    float* y;             /* [N,d] fp32 output                                             */
+    void* qkv16;          /* [N,3d] bf16 out (saved for the backward / scratch)            */
+    void* attn16;         /* [N,d]  bf16 out (saved for the backward / scratch)            */
+    float* lse;           /* [H,N] out, or NULL for a forward without backward             */
+    void* qpack;          /* NULL, or moma_infonce_qpack_bytes(N,d) bytes: packed y * qpack_scale for moma_infonce_fused_q */
+    float qpack_scale;
+    int x_dtype;          /* MOMA_DT_F32 / MOMA_DT_BF16: storage type of x (a bf16 x -- the output of a bf16-autocast head -- is
+                             consumed as it stands: the products round x to bf16 either way, the values are identical)        */
+} moma_mha_module_t;
+size_t moma_mha_pack_bytes(int d);
+int moma_mha_pack_weights(const float* w_qkv, const float* w_proj, void* pack, int d, int with_transposed,
+                          moma_stream_t stream);
+int moma_mha_fwd_fast(const moma_mha_module_t* modules, int n_modules, int N, int d, int H, moma_stream_t stream);
+size_t moma_mha_bwd_fast_workspace_bytes(int N, int d, int H);
+int moma_mha_bwd_fast(const void* pack, const void* x, int x_dtype, const void* qkv16, const void* attn16, const float* lse,
+                      const float* dy, float* dx, float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj,
+                      void* workspace, size_t workspace_bytes, int N, int d, int H, moma_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BN  BatchNorm2d + fused activation on NCHW activations -- the `_swish(_bn(conv(x)))` pairs of the

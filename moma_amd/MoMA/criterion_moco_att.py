@@ -49,12 +49,33 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.precision = precision
+        self._pack = ops.MhaPack()          # bf16 weight copies of the fast path (not a parameter, not in the state dict)
 
-    def forward(self, x):
+    def invalidate_pack(self):
+        """Call after writing the weights through anything that bypasses autograd's version counters."""
+        self._pack.invalidate()
+
+    def forward(self, x, qpack=None):
         if x.dim() != 2:
             raise ValueError("Attention expects [N, dim] (batch rows are the tokens)")
-        return ops.mha(x.float(), self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
-                       self.num_heads, self.precision)
+        return ops.mha(self._input(x), self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                       self.num_heads, self.precision, self._pack, qpack)
+
+    @staticmethod
+    def _input(x):
+        # a bf16 x (the output of a head under bf16 autocast) goes to the kernels as it stands: they round x to bf16 at
+        # operand staging either way, so the values are identical and the bytes half; everything else is taken as fp32
+        return x if x.dtype == torch.bfloat16 else x.float()
+
+    @staticmethod
+    def forward_group(modules, xs):
+        """[m(x) for m, x in zip(modules, xs)] in one group of launches where possible (no-grad key side of the step:
+        atts_k and atts_queue, reference helper/loops_moma.py:327-329)."""
+        m0 = modules[0]
+        if any(m.num_heads != m0.num_heads or m.precision != m0.precision for m in modules):
+            return [m(x) for m, x in zip(modules, xs)]
+        return ops.mha_group([(Attention._input(x), m.qkv.weight, m.qkv.bias, m.proj.weight, m.proj.bias, m._pack)
+                              for m, x in zip(modules, xs)], m0.num_heads, m0.precision)
 
 
 def _head(kind, in_dim, feat_dim):

@@ -101,7 +101,16 @@ class MoCo(BaseMoCo):
         if mem.is_cuda:
             ops.queue_prefetch(mem, stream)
 
-    def forward_fused(self, q, k, all_k=None):
+    def qpack(self, B, d, device):
+        """A packed-query buffer for the producer of q (Attention.forward(x, qpack=...)): K2 then runs no pre-pack launch.
+        None when the one-pass kernel does not take this configuration."""
+        if ops.prec_code(self.precision) != ops.PREC_BF16:
+            return None
+        if getattr(self, "_qpack", None) is None:
+            self._qpack = ops.QPack()
+        return self._qpack.prepare(B, d, self.T, device)
+
+    def forward_fused(self, q, k, all_k=None, qpack=None):
         """One pass over the queue -> (loss_kd, top-1 accuracy in percent [1]); then enqueue.
 
         loss_kd == CrossEntropyLoss(logits, zeros) of the reference loop; its gradient w.r.t. q is produced
@@ -110,7 +119,7 @@ class MoCo(BaseMoCo):
         shadow = None
         if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
             shadow = self._bf16_shadow()
-        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision)
+        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack)
         all_k = all_k if all_k is not None else k
         if shadow is not None:
             # fp32 `memory` and its bf16 mirror in ONE launch (same rows, rounded to bf16: the mirror stays exact)

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MOMA_HIP_LIB", os.path.join(_HERE, "lib", "libmoma_hi
 PREC_F32, PREC_BF16 = 0, 1
 DT_F32, DT_BF16 = 0, 1
 MHA_SAVE_PROBS, MHA_SAVE_LSE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 EMA_BLOCK_ELEMS = 4096
 
 _p = C.c_void_p
@@ -37,8 +37,15 @@ SIGNATURES = {
     "moma_infonce_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
-    "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "moma_infonce_qpack_bytes": (_z, [_i, _i]),
+    "moma_infonce_fused_q": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
+    "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "moma_mha_saved_state": (_i, [_i, _i, _i, _i]),
+    "moma_mha_pack_bytes": (_z, [_i]),
+    "moma_mha_pack_weights": (_i, [_p, _p, _p, _i, _i, _p]),
+    "moma_mha_fwd_fast": (_i, [_p, _i, _i, _i, _i, _p]),
+    "moma_mha_bwd_fast_workspace_bytes": (_z, [_i, _i, _i]),
+    "moma_mha_bwd_fast": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _p]),
     "moma_dwconv_workspace_bytes": (_z, [_i, _i]),
     "moma_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
     "moma_dwconv_bwd_data": (_i, [_p, _p, _p] + [_i] * 11 + [_p]),
@@ -50,8 +57,16 @@ SIGNATURES = {
     "moma_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p]),
     "moma_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p, _p]),
     "moma_mha_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
-    "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
 }
+
+
+
+class MhaModule(C.Structure):
+    """moma_mha_module_t of include/moma_hip.h (one module of a grouped moma_mha_fwd_fast call)."""
+    _fields_ = [("x", _p), ("pack", _p), ("b_qkv", _p), ("b_proj", _p), ("y", _p), ("qkv16", _p), ("attn16", _p),
+                ("lse", _p), ("qpack", _p), ("qpack_scale", _f), ("x_dtype", _i)]
+
 
 _lib = None
 

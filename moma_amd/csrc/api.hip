@@ -146,15 +146,26 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
                           float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
                           size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin,
                           void* ev_end) {
+    return moma_infonce_fused_q(q, nullptr, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, workspace_bytes,
+                                qdtype, prec, stream, ev_begin, ev_end);
+}
+
+size_t moma_infonce_qpack_bytes(int B, int d) { return infonce_qpack_bytes(B, d); }
+
+int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
+                         float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                         size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end) {
     if (!q || !k || !queue || !loss_rows || !lse || !top1 || !workspace) return MOMA_E_NULL;
     if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
     if (workspace_bytes < moma_infonce_fused_workspace_bytes(B, d, K, qdtype, prec)) return MOMA_E_WORKSPACE;
     if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (q_packed && (misaligned(q_packed, 16) || infonce_qpack_bytes(B, d) == 0 || !infonce_flash_supported(B, d, K, qdtype, prec)))
+        return q_packed && misaligned(q_packed, 16) ? MOMA_E_ALIGN : MOMA_E_UNSUPPORTED;
     if (infonce_flash_supported(B, d, K, qdtype, prec))
         return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,
-                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
+                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed));
     // staged path (any shape, exact fp32 available): logits -> row reduction -> gradient product
     float* logits = (float*)workspace;
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, st);
@@ -168,17 +179,15 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
 
 int moma_mha_saved_state(int N, int d, int H, int prec) {
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0 || bad_prec(prec)) return MOMA_E_SHAPE;
-    return mha_core_fused_supported(N, d, H, prec) ? MOMA_MHA_SAVE_LSE : MOMA_MHA_SAVE_PROBS;
+    return mha_fast_supported(N, d, H, prec) ? MOMA_MHA_SAVE_LSE : MOMA_MHA_SAVE_PROBS;
 }
 
 int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const float* w_proj, const float* b_proj,
-                 float* y, float* qkv, float* probs, float* lse, float* attn_out, int N, int d, int H, int prec,
+                 float* y, float* qkv, float* probs, float* attn_out, int N, int d, int H, int prec,
                  moma_stream_t stream) {
-    if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !attn_out) return MOMA_E_NULL;
+    if (!x || !w_qkv || !w_proj || !b_proj || !y || !qkv || !attn_out || !probs) return MOMA_E_NULL;
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
     if (bad_prec(prec)) return MOMA_E_DTYPE;
-    const bool fused = mha_core_fused_supported(N, d, H, prec);
-    if (!probs && !fused) return MOMA_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int hd = d / H;
     const float scale = 1.0f / sqrtf((float)hd);
@@ -186,13 +195,6 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
     GemmArgs g = gemm(x, w_qkv, qkv, N, 3 * d, d, d, d, 3L * d, 0, 0, 1.f, prec);
     g.bias = b_qkv;
     MOMA_TRY(launch_gemm(g, st));
-    if (fused) {
-        // one launch per module: scores, softmax and context per head (:159-163), mha_fused.hip; keeps lse, never P
-        MOMA_TRY(launch_mha_core_fwd(qkv, attn_out, lse, N, d, H, st));
-        g = gemm(attn_out, w_proj, y, N, d, d, d, d, d, 0, 0, 1.f, prec);
-        g.bias = b_proj;
-        return hip_rc(launch_gemm(g, st));
-    }
     // per head: S = (q k^T) * scale                          (:159)
     g = gemm(qkv, qkv + d, probs, N, N, hd, 3L * d, 3L * d, N, 0, 0, scale, prec);
     g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
@@ -210,28 +212,25 @@ int moma_mha_fwd(const float* x, const float* w_qkv, const float* b_qkv, const f
 
 size_t moma_mha_bwd_workspace_bytes(int N, int d, int H, int prec) {
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0 || bad_prec(prec)) return 0;
-    // dA [N,d] + dqkv [N,3d] + (fused: D [H,N] | staged: dP [H,N,N])
-    const size_t mid = mha_core_fused_supported(N, d, H, prec) ? (size_t)H * N : (size_t)H * N * N;
-    return align_up(((size_t)N * d + mid + (size_t)N * 3 * d) * sizeof(float), 256);
+    // dA [N,d] + dP [H,N,N] + dqkv [N,3d]
+    return align_up(((size_t)N * d + (size_t)H * N * N + (size_t)N * 3 * d) * sizeof(float), 256);
 }
 
 int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const float* qkv, const float* probs,
-                 const float* lse, const float* attn_out, const float* dy, float* dx, float* dw_qkv, float* db_qkv,
+                 const float* attn_out, const float* dy, float* dx, float* dw_qkv, float* db_qkv,
                  float* dw_proj, float* db_proj, void* workspace, size_t workspace_bytes, int N, int d, int H, int prec,
                  moma_stream_t stream) {
-    if (!x || !w_qkv || !w_proj || !qkv || !attn_out || !dy || !workspace) return MOMA_E_NULL;
+    if (!x || !w_qkv || !w_proj || !qkv || !attn_out || !dy || !workspace || !probs) return MOMA_E_NULL;
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
     if (bad_prec(prec)) return MOMA_E_DTYPE;
-    const bool fused = mha_core_fused_supported(N, d, H, prec);
-    if (fused ? !lse : !probs) return MOMA_E_NULL;
     if (workspace_bytes < moma_mha_bwd_workspace_bytes(N, d, H, prec)) return MOMA_E_WORKSPACE;
     if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int hd = d / H;
     const float scale = 1.0f / sqrtf((float)hd);
     float* dA = (float*)workspace;
-    float* dP = dA + (size_t)N * d;                                           // fused: the D [H,N] scratch
-    float* dqkv = dP + (fused ? (size_t)H * N : (size_t)H * N * N);
+    float* dP = dA + (size_t)N * d;
+    float* dqkv = dP + (size_t)H * N * N;
     GemmArgs g;
     // proj: dWproj = dy^T a ; dbproj = colsum(dy) ; dA = dy Wproj
     bool db_done = false;
@@ -243,28 +242,23 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
     if (db_proj && !db_done) MOMA_TRY(launch_colsum(dy, db_proj, N, d, d, st));
     g = gemm(dy, w_proj, dA, N, d, d, d, d, d, 0, 1, 1.f, prec);
     MOMA_TRY(launch_gemm(g, st));
-    if (fused) {
-        // fused per-head backward core from the row log-sum-exp: D = rowdot(dA, a), then dQ | dK | dV in one launch
-        MOMA_TRY(launch_mha_core_bwd(qkv, lse, attn_out, dA, dP, dqkv, N, d, H, st));
-    } else {
-        // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
-        g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
-        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-        MOMA_TRY(launch_gemm(g, st));
-        // per head: dP = dA_h V^T
-        g = gemm(dA, qkv + 2 * d, dP, N, N, hd, d, 3L * d, N, 0, 0, 1.f, prec);
-        g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
-        MOMA_TRY(launch_gemm(g, st));
-        // dS = P * (dP - rowsum(dP*P)) * scale   (in place on dP)
-        MOMA_TRY(launch_softmax_bwd_rows(probs, dP, (long)H * N, N, scale, st));
-        // per head: dQ = dS K ; dK = dS^T Q
-        g = gemm(dP, qkv + d, dqkv, N, hd, N, N, 3L * d, 3L * d, 0, 1, 1.f, prec);
-        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-        MOMA_TRY(launch_gemm(g, st));
-        g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
-        g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
-        MOMA_TRY(launch_gemm(g, st));
-    }
+    // per head: dV = P^T dA_h  -> dqkv[:, 2d + h*hd ...]
+    g = gemm(probs, dA, dqkv + 2 * d, N, hd, N, N, d, 3L * d, 1, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    // per head: dP = dA_h V^T
+    g = gemm(dA, qkv + 2 * d, dP, N, N, hd, d, 3L * d, N, 0, 0, 1.f, prec);
+    g.batch = H; g.strideA = hd; g.strideB = hd; g.strideC = (long)N * N;
+    MOMA_TRY(launch_gemm(g, st));
+    // dS = P * (dP - rowsum(dP*P)) * scale   (in place on dP)
+    MOMA_TRY(launch_softmax_bwd_rows(probs, dP, (long)H * N, N, scale, st));
+    // per head: dQ = dS K ; dK = dS^T Q
+    g = gemm(dP, qkv + d, dqkv, N, hd, N, N, 3L * d, 3L * d, 0, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
+    g = gemm(dP, qkv, dqkv + d, N, hd, N, N, 3L * d, 3L * d, 1, 1, 1.f, prec);
+    g.batch = H; g.strideA = (long)N * N; g.strideB = hd; g.strideC = hd;
+    MOMA_TRY(launch_gemm(g, st));
     // qkv linear: dWqkv = dqkv^T x ; dbqkv = colsum(dqkv) ; dx = dqkv Wqkv
     db_done = false;
     if (dw_qkv) {
@@ -278,6 +272,55 @@ int moma_mha_bwd(const float* x, const float* w_qkv, const float* w_proj, const 
         MOMA_TRY(launch_gemm(g, st));
     }
     return MOMA_OK;
+}
+
+// ---- K1 fast path (k1_fast.hip) ----------------------------------------------------------------------------------
+size_t moma_mha_pack_bytes(int d) { return d > 0 ? (size_t)16 * d * d : 0; }
+
+int moma_mha_pack_weights(const float* w_qkv, const float* w_proj, void* pack, int d, int with_transposed,
+                          moma_stream_t stream) {
+    if (!w_qkv || !w_proj || !pack) return MOMA_E_NULL;
+    if (d <= 0 || d % 16 != 0) return MOMA_E_SHAPE;
+    if (misaligned(pack, 16) || misaligned(w_qkv, 4) || misaligned(w_proj, 4)) return MOMA_E_ALIGN;
+    return hip_rc(launch_mha_pack(w_qkv, w_proj, pack, d, with_transposed != 0, (hipStream_t)stream));
+}
+
+int moma_mha_fwd_fast(const moma_mha_module_t* mods, int n_modules, int N, int d, int H, moma_stream_t stream) {
+    if (!mods) return MOMA_E_NULL;
+    if (n_modules < 1 || n_modules > 4 || N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
+    if (!mha_fast_supported(N, d, H, MOMA_PREC_BF16)) return MOMA_E_UNSUPPORTED;
+    for (int i = 0; i < n_modules; ++i) {
+        const moma_mha_module_t& m = mods[i];
+        if (!m.x || !m.pack || !m.b_proj || !m.y || !m.qkv16 || !m.attn16) return MOMA_E_NULL;
+        if (bad_dt(m.x_dtype)) return MOMA_E_DTYPE;
+        if (misaligned(m.x, 16) || misaligned(m.pack, 16) || misaligned(m.y, 16) || misaligned(m.qkv16, 16) ||
+            misaligned(m.attn16, 16) || misaligned(m.b_proj, 16) || (m.b_qkv && misaligned(m.b_qkv, 16)) ||
+            (m.qpack && misaligned(m.qpack, 16)))
+            return MOMA_E_ALIGN;
+    }
+    return hip_rc(launch_mha_fwd_fast(mods, n_modules, N, d, H, (hipStream_t)stream));
+}
+
+size_t moma_mha_bwd_fast_workspace_bytes(int N, int d, int H) {
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return 0;
+    return mha_bwd_fast_workspace_bytes(N, d);
+}
+
+int moma_mha_bwd_fast(const void* pack, const void* x, int x_dtype, const void* qkv16, const void* attn16, const float* lse,
+                      const float* dy, float* dx, float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj,
+                      void* workspace, size_t workspace_bytes, int N, int d, int H, moma_stream_t stream) {
+    if (!pack || !x || !qkv16 || !attn16 || !lse || !dy || !workspace) return MOMA_E_NULL;
+    if (N <= 0 || d <= 0 || H <= 0 || d % H != 0) return MOMA_E_SHAPE;
+    if (!mha_fast_supported(N, d, H, MOMA_PREC_BF16)) return MOMA_E_UNSUPPORTED;
+    if (bad_dt(x_dtype)) return MOMA_E_DTYPE;
+    if ((db_qkv && !dw_qkv) || (db_proj && !dw_proj)) return MOMA_E_UNSUPPORTED;      // a bias gradient rides on its weight gradient
+    if (workspace_bytes < mha_bwd_fast_workspace_bytes(N, d)) return MOMA_E_WORKSPACE;
+    if (misaligned(workspace, 16) || misaligned(pack, 16) || misaligned(x, 16) || misaligned(qkv16, 16) ||
+        misaligned(attn16, 16) || misaligned(dy, 16) || (dx && misaligned(dx, 16)) || (dw_qkv && misaligned(dw_qkv, 8)) ||
+        (dw_proj && misaligned(dw_proj, 8)))
+        return MOMA_E_ALIGN;
+    return hip_rc(launch_mha_bwd_fast(pack, x, x_dtype, qkv16, attn16, lse, dy, dx, dw_qkv, db_qkv, dw_proj, db_proj, workspace, N, d,
+                                      H, (hipStream_t)stream));
 }
 
 size_t moma_bn_workspace_bytes(int C) { return C > 0 ? align_up(bn_workspace_floats(C) * sizeof(float), 256) : 0; }

@@ -89,13 +89,18 @@ bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec);
 size_t infonce_flash_workspace_bytes(int B, int d, int K);
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                                hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
+                                const void* q_packed = nullptr);
+size_t infonce_qpack_bytes(int B, int d);
 
-// ---- mha_fused.hip (fused per-head attention core, forward) ---------------------------------------
-bool mha_core_fused_supported(int N, int d, int H, int prec);
-hipError_t launch_mha_core_fwd(const float* qkv, float* attn_out, float* lse, int N, int d, int H, hipStream_t st);
-hipError_t launch_mha_core_bwd(const float* qkv, const float* lse, const float* attn_out, const float* dA, float* D,
-                               float* dqkv, int N, int d, int H, hipStream_t st);
+// ---- k1_fast.hip (batch-token attention, bf16 fast path) -------------------------------------------
+bool mha_fast_supported(int N, int d, int H, int prec);
+hipError_t launch_mha_pack(const float* w_qkv, const float* w_proj, void* pack, int d, int with_t, hipStream_t st);
+hipError_t launch_mha_fwd_fast(const moma_mha_module_t* mods, int n_modules, int N, int d, int H, hipStream_t st);
+size_t mha_bwd_fast_workspace_bytes(int N, int d);
+hipError_t launch_mha_bwd_fast(const void* pack, const void* x, int x_dtype, const void* qkv16, const void* attn16, const float* lse,
+                               const float* dy, float* dx, float* dw_qkv, float* db_qkv, float* dw_proj, float* db_proj,
+                               void* workspace, int N, int d, int H, hipStream_t st);
 
 // ---- bn.hip (BatchNorm2d + activation, NCHW) ------------------------------------------------------
 size_t bn_workspace_floats(int C);

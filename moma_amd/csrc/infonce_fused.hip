@@ -1666,9 +1666,16 @@ void set_lds_attrs() {
 }
 }  // namespace
 
+size_t infonce_qpack_bytes(int B, int d) {
+    if (B < 1 || !one_pass_dim(d)) return 0;
+    return (size_t)plan(B, 1).Bpad * d * 2;
+}
+
+// q_packed (nullable, one-pass widths only): q * inv_T * log2(e) as bf16 in infonce_qpack_kernel's layout, written by the
+// producer of q (K1's proj epilogue, k1_fast.hip) -- the pre-pack launch is skipped.
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed) {
     const FlashPlan p = plan(B, K);
     if (p.nchunk > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;
     const size_t rows = (size_t)p.nchunk * p.Bpad;
@@ -1772,9 +1779,10 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     }
     const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
 #define MOMA_FLASH_ARGS qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part
+    if (q_packed != nullptr) qpack = (uint4*)q_packed;
 #define MOMA_FLASH_LAUNCH(DD)                                                                             \
     do {                                                                                                  \
-        hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
+        if (q_packed == nullptr) hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
         /* measurement events ride on the dispatch itself (kernel begin / end timestamps, what rocprofv3 reports): events   */ \
         /* recorded around the launch add the latency of two event packets, ~3 us on a 36 us kernel                        */ \
         if (dq) hipExtLaunchKernelGGL((infonce_flash_kernel<DD, true>), grid, block, lds, st, ev_begin, ev_end, 0, MOMA_FLASH_ARGS);  \

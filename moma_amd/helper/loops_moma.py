@@ -118,9 +118,8 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                 kk, akk = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
             kk, akk = kk.float(), akk.float()
             if opt.attn == "self" and not mocoatt:                                        # K1, key side (:327-329)
-                with torch.no_grad():
-                    kk = criterion_kd.atts_k(kk)
-                    akk = criterion_kd.atts_queue(akk)
+                with torch.no_grad():           # one group of launches for the two key-side modules
+                    kk, akk = criterion_kd.atts_k.forward_group([criterion_kd.atts_k, criterion_kd.atts_queue], [kk, akk])
             return lt.float(), kk, akk
 
         if overlap:
@@ -143,6 +142,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
 
         loss_cls = criterion_cls(logit_s, labels)
         loss_div = criterion_div(logit_s, logit_t)
+        qp = None
 
         if opt.distill == "kd":
             loss_kd = 0
@@ -162,7 +162,9 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                     # the queue was last read a whole step ago: sweep it into the Infinity Cache on the side stream while the
                     # (launch-latency-bound) attention module runs here; K2 then streams it at cache latency
                     contrast.prefetch(stream=side)
-                f_s = criterion_kd.atts_q(f_s)
+                # atts_q's proj epilogue also leaves q in the packed bf16 layout K2 loads it in (no pre-pack launch in K2)
+                qp = contrast.qpack(f_s.shape[0], f_s.shape[1], f_s.device) if (fused and hasattr(contrast, "qpack")) else None
+                f_s = criterion_kd.atts_q(f_s, qpack=qp)
 
             if mocoatt:
                 # --mem MoCoAtt: the memory applies the teacher-student cross-attention variant itself
@@ -175,7 +177,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
                 c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
                 loss_kd = c_losses[0]
             elif fused:                                                                   # K2 + K3
-                loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k)
+                loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k, **({"qpack": qp} if qp is not None else {}))
             else:                                                                         # reference sequence (:331-335)
                 criterion = nn.CrossEntropyLoss()
                 output = contrast(q=f_s, k=k, all_k=all_k)

@@ -229,11 +229,40 @@ def infonce_logits(q, k, queue, T: float, prec="fp32") -> torch.Tensor:
     return _InfoNCELogits.apply(q, k, queue, float(T), prec_code(prec))
 
 
+class QPack:
+    """The query of K2 in the packed bf16 MFMA-operand layout (moma_infonce_fused_q), written by the producer of q -- the proj
+    epilogue of the attention module atts_q (moma_mha_fwd_fast) -- so that K2 runs no pre-pack launch.  One persistent buffer
+    per (B, d): its pad rows stay zero.  `src` remembers which q tensor / temperature the image was made from; K2 ignores
+    the image unless it is handed exactly that tensor."""
+
+    def __init__(self):
+        self.buf, self.shape, self.scale, self.src = None, None, None, None
+
+    def prepare(self, B: int, d: int, T: float, device):
+        """-> (buffer, scale) for Attention.forward(x, qpack=...), or None when K2 takes no pre-packed query at this width."""
+        lib = _lib.load()
+        nbytes = lib.moma_infonce_qpack_bytes(B, d)
+        if nbytes == 0:
+            return None
+        if self.buf is None or self.shape != (B, d) or self.buf.device != device:
+            self.buf = torch.zeros(nbytes, device=device, dtype=torch.uint8)
+            self.shape = (B, d)
+        self.scale, self.T = (1.0 / T) * 1.4426950408889634, float(T)
+        self.src = None
+        return self
+
+    def written_from(self, q: torch.Tensor, T: float):
+        self.src = (q.data_ptr(), q._version, tuple(q.shape), float(T))
+
+    def matches(self, q: torch.Tensor, T: float) -> bool:
+        return self.buf is not None and self.src == (q.data_ptr(), q._version, tuple(q.shape), float(T))
+
+
 class _InfoNCEFused(torch.autograd.Function):
     """One pass over the queue: per-row CE(label 0) loss, lse, top-1 flag and d(sum loss)/dq."""
 
     @staticmethod
-    def forward(ctx, q, k, queue, T, prec):
+    def forward(ctx, q, k, queue, T, prec, qpack=None):
         lib = _lib.load()
         q = q.contiguous(); k = k.contiguous()
         _check_qk(q, k, queue)
@@ -250,9 +279,9 @@ class _InfoNCEFused(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         ev0, ev1 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None)
         with _timed("moma_infonce_fused"):
-            check(lib.moma_infonce_fused_ex(_ptr(q), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T), _ptr(loss_rows),
-                                            _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec, _stream(),
-                                            C.c_void_p(ev0), C.c_void_p(ev1)),
+            check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
+                                           _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec,
+                                           _stream(), C.c_void_p(ev0), C.c_void_p(ev1)),
                   "moma_infonce_fused")
         if need_grad:
             ctx.save_for_backward(dq)
@@ -262,73 +291,179 @@ class _InfoNCEFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_lse, g_top1):
         (dq,) = ctx.saved_tensors
-        return dq * g_loss.unsqueeze(1), None, None, None, None
+        return dq * g_loss.unsqueeze(1), None, None, None, None, None
 
 
-def infonce_fused(q, k, queue, T: float, prec="fp32") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """-> (loss_rows [B], lse [B], top1 [B] int32).  loss_kd = loss_rows.mean()."""
-    return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec))
+def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (loss_rows [B], lse [B], top1 [B] int32).  loss_kd = loss_rows.mean().
+    qpack: a QPack that the producer of q filled (ignored unless it was written from exactly this q and T)."""
+    buf = None
+    if qpack is not None and q.is_contiguous() and qpack.matches(q, T) and queue.dtype == torch.bfloat16 \
+            and prec_code(prec) == PREC_BF16:
+        buf = qpack.buf
+    return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec), buf)
 
 
 # ------------------------------------------------------------------------------------------------
 # K1 batch-token multi-head attention   (MoMA/criterion_moco_att.py:153-167)
 # ------------------------------------------------------------------------------------------------
+class MhaPack:
+    """bf16 weight pack of one attention module for the fast path ([Wqkv | Wproj | Wqkv^T | Wproj^T], moma_mha_pack_weights):
+    rebuilt -- into a NEW buffer, a pending backward keeps the one its forward used -- when the fp32 weights were replaced or
+    modified in place (optimizer.step(), load_state_dict: the tensors' version counters move).  A writer that bypasses
+    autograd's version counter (a raw-pointer kernel) must call invalidate()."""
+
+    def __init__(self):
+        self.buf, self.key, self.has_t = None, None, False
+
+    def invalidate(self):
+        self.buf = None
+
+    def get(self, w_qkv: torch.Tensor, w_proj: torch.Tensor, need_t: bool) -> torch.Tensor:
+        key = (w_qkv.data_ptr(), w_qkv._version, w_proj.data_ptr(), w_proj._version, w_qkv.device)
+        if self.buf is None or key != self.key or (need_t and not self.has_t):
+            lib = _lib.load()
+            d = w_proj.shape[0]
+            buf = torch.empty(lib.moma_mha_pack_bytes(d), device=w_qkv.device, dtype=torch.uint8)
+            check(lib.moma_mha_pack_weights(_ptr(w_qkv), _ptr(w_proj), _ptr(buf), d, int(need_t), _stream()),
+                  "moma_mha_pack_weights")
+            self.buf, self.key, self.has_t = buf, key, bool(need_t)
+        return self.buf
+
+
+def _mha_check(x, w_qkv, b_qkv, w_proj, b_proj, H):
+    _dev(x, "x", None)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"x: expected float32 or bfloat16, got {x.dtype}")
+    for t, nm in ((w_qkv, "qkv.weight"), (w_proj, "proj.weight"), (b_proj, "proj.bias")):
+        _dev(t, nm)
+    if b_qkv is not None:
+        _dev(b_qkv, "qkv.bias")
+    N, d = x.shape
+    if w_qkv.shape != (3 * d, d) or w_proj.shape != (d, d) or d % H:
+        raise ValueError(f"bad attention shapes: x {tuple(x.shape)} Wqkv {tuple(w_qkv.shape)} H={H}")
+    return N, d
+
+
+def _mha_fast_fwd(items, H, want_lse, qpacks=None):
+    """One grouped moma_mha_fwd_fast call.  items: [(x, pack, b_qkv, b_proj)], equal shapes.  -> [(y, qkv16, attn16, lse)]"""
+    lib = _lib.load()
+    N, d = items[0][0].shape
+    dev = items[0][0].device
+    mods = (_lib.MhaModule * len(items))()
+    outs = []
+    for i, (x, pack, b_qkv, b_proj) in enumerate(items):
+        y = torch.empty(N, d, device=dev, dtype=torch.float32)
+        qkv16 = torch.empty(N, 3 * d, device=dev, dtype=torch.bfloat16)
+        attn16 = torch.empty(N, d, device=dev, dtype=torch.bfloat16)
+        lse = torch.empty(H, N, device=dev, dtype=torch.float32) if want_lse else None
+        qp = qpacks[i] if qpacks is not None else None       # a prepared QPack
+        m = mods[i]
+        m.x, m.pack, m.b_qkv, m.b_proj = x.data_ptr(), pack.data_ptr(), (0 if b_qkv is None else b_qkv.data_ptr()), b_proj.data_ptr()
+        m.y, m.qkv16, m.attn16, m.lse = y.data_ptr(), qkv16.data_ptr(), attn16.data_ptr(), (0 if lse is None else lse.data_ptr())
+        m.qpack, m.qpack_scale = (0, 0.0) if qp is None else (qp.buf.data_ptr(), float(qp.scale))
+        m.x_dtype = DT_BF16 if x.dtype == torch.bfloat16 else DT_F32
+        outs.append((y, qkv16, attn16, lse))
+    with _timed("moma_mha_fwd"):
+        check(lib.moma_mha_fwd_fast(C.cast(mods, C.c_void_p), len(items), N, d, H, _stream()), "moma_mha_fwd_fast")
+    return outs
+
+
 class _MHA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_qkv, b_qkv, w_proj, b_proj, H, prec, grad_mode):
+    def forward(ctx, x, w_qkv, b_qkv, w_proj, b_proj, H, prec, grad_mode, holder, qpack):
         lib = _lib.load()
         x = x.contiguous()
-        for t, nm in ((x, "x"), (w_qkv, "qkv.weight"), (w_proj, "proj.weight"), (b_proj, "proj.bias")):
-            _dev(t, nm)
-        if b_qkv is not None:
-            _dev(b_qkv, "qkv.bias")
-        N, d = x.shape
-        if w_qkv.shape != (3 * d, d) or w_proj.shape != (d, d) or d % H:
-            raise ValueError(f"bad attention shapes: x {tuple(x.shape)} Wqkv {tuple(w_qkv.shape)} H={H}")
+        N, d = _mha_check(x, w_qkv, b_qkv, w_proj, b_proj, H)
         dev = x.device
+        ctx.x_dtype = x.dtype
+        need_bwd = grad_mode and any(ctx.needs_input_grad)      # (grad mode is always off inside forward)
+        fast = lib.moma_mha_saved_state(N, d, H, prec) == _lib.MHA_SAVE_LSE
+        ctx.H, ctx.prec, ctx.has_bqkv, ctx.fast = H, prec, b_qkv is not None, fast
+        if fast:
+            # bf16 fast path: the forward keeps qkv / attn_out as bf16 and the row log-sum-exp [H,N]; P is recomputed per tile
+            pack = (holder if holder is not None else MhaPack()).get(w_qkv, w_proj, need_bwd)
+            (y, qkv16, attn16, lse), = _mha_fast_fwd([(x, pack, b_qkv, b_proj)], H, need_bwd,
+                                                     None if qpack is None else [qpack])
+            if need_bwd:
+                ctx.save_for_backward(x, pack, qkv16, attn16, lse)
+            if qpack is not None:
+                qpack.written_from(y, qpack.T)
+            return y
+        x = x.float()                       # (a bf16 x is consumed as it stands by the fast path only; a packed-q request is dropped)
+        # staged path (exact fp32, odd head dims): keeps the probabilities [H,N,N]
         y = torch.empty(N, d, device=dev, dtype=torch.float32)
         qkv = torch.empty(N, 3 * d, device=dev, dtype=torch.float32)
-        need_bwd = grad_mode and any(ctx.needs_input_grad)      # (grad mode is always off inside forward)
-        # what the backward needs besides qkv / attn_out: the fused per-head core keeps the row log-sum-exp [H,N] (it recomputes
-        # P per tile); the staged path (exact fp32, odd head dims) the probabilities [H,N,N] -- which it also computes through
-        save_lse = lib.moma_mha_saved_state(N, d, H, prec) == _lib.MHA_SAVE_LSE
-        probs = None if save_lse else torch.empty(H, N, N, device=dev, dtype=torch.float32)
-        lse = torch.empty(H, N, device=dev, dtype=torch.float32) if (save_lse and need_bwd) else None
+        probs = torch.empty(H, N, N, device=dev, dtype=torch.float32)
         attn_out = torch.empty(N, d, device=dev, dtype=torch.float32)
         with _timed("moma_mha_fwd"):
             check(lib.moma_mha_fwd(_ptr(x), _ptr(w_qkv), _ptr(b_qkv), _ptr(w_proj), _ptr(b_proj), _ptr(y), _ptr(qkv),
-                                   _ptr(probs), _ptr(lse), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
+                                   _ptr(probs), _ptr(attn_out), N, d, H, prec, _stream()), "moma_mha_fwd")
         if need_bwd:
-            ctx.save_for_backward(x, w_qkv, w_proj, qkv, lse if save_lse else probs, attn_out)
-        ctx.H, ctx.prec, ctx.has_bqkv, ctx.save_lse = H, prec, b_qkv is not None, save_lse
+            ctx.save_for_backward(x, w_qkv, w_proj, qkv, probs, attn_out)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w_qkv, w_proj, qkv, state, attn_out = ctx.saved_tensors
-        probs, lse = (None, state) if ctx.save_lse else (state, None)
         dy = dy.contiguous()
-        N, d = x.shape
         H = ctx.H
-        dev = x.device
         need = ctx.needs_input_grad
-        dx = torch.empty_like(x) if need[0] else None
-        dw_qkv = torch.empty_like(w_qkv) if need[1] else None
+        if ctx.fast:
+            x, pack, qkv16, attn16, lse = ctx.saved_tensors
+        else:
+            x, w_qkv, w_proj, qkv, probs, attn_out = ctx.saved_tensors
+        N, d = x.shape
+        dev = x.device
+        dx = torch.empty(N, d, device=dev, dtype=torch.float32) if need[0] else None
+        dw_qkv = torch.empty(3 * d, d, device=dev, dtype=torch.float32) if need[1] else None
         db_qkv = torch.empty(3 * d, device=dev, dtype=torch.float32) if (need[2] and ctx.has_bqkv) else None
-        dw_proj = torch.empty_like(w_proj) if need[3] else None
+        dw_proj = torch.empty(d, d, device=dev, dtype=torch.float32) if need[3] else None
         db_proj = torch.empty(d, device=dev, dtype=torch.float32) if need[4] else None
-        ws_bytes = lib.moma_mha_bwd_workspace_bytes(N, d, H, ctx.prec)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        with _timed("moma_mha_bwd"):
-            check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(lse), _ptr(attn_out),
-                                   _ptr(dy), _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
-                                   ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
-        return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None, None
+        if ctx.fast:
+            # a bias gradient rides on its weight gradient's launch: compute the weight gradient too if only the bias wants one
+            t_wq = dw_qkv if (dw_qkv is not None or db_qkv is None) else torch.empty(3 * d, d, device=dev, dtype=torch.float32)
+            t_wp = dw_proj if (dw_proj is not None or db_proj is None) else torch.empty(d, d, device=dev, dtype=torch.float32)
+            ws = torch.empty(lib.moma_mha_bwd_fast_workspace_bytes(N, d, H), device=dev, dtype=torch.uint8)
+            with _timed("moma_mha_bwd"):
+                check(lib.moma_mha_bwd_fast(_ptr(pack), _ptr(x), DT_BF16 if x.dtype == torch.bfloat16 else DT_F32, _ptr(qkv16), _ptr(attn16), _ptr(lse), _ptr(dy), _ptr(dx),
+                                            _ptr(t_wq), _ptr(db_qkv), _ptr(t_wp), _ptr(db_proj), _ptr(ws), ws.numel(), N, d, H,
+                                            _stream()), "moma_mha_bwd_fast")
+        else:
+            ws = torch.empty(lib.moma_mha_bwd_workspace_bytes(N, d, H, ctx.prec), device=dev, dtype=torch.uint8)
+            with _timed("moma_mha_bwd"):
+                check(lib.moma_mha_bwd(_ptr(x), _ptr(w_qkv), _ptr(w_proj), _ptr(qkv), _ptr(probs), _ptr(attn_out),
+                                       _ptr(dy), _ptr(dx), _ptr(dw_qkv), _ptr(db_qkv), _ptr(dw_proj), _ptr(db_proj), _ptr(ws),
+                                       ws.numel(), N, d, H, ctx.prec, _stream()), "moma_mha_bwd")
+        if dx is not None and dx.dtype != ctx.x_dtype:
+            dx = dx.to(ctx.x_dtype)
+        return dx, dw_qkv, db_qkv, dw_proj, db_proj, None, None, None, None, None
 
 
-def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads: int, prec="fp32") -> torch.Tensor:
-    return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec), torch.is_grad_enabled())
+def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads: int, prec="fp32", pack: "MhaPack | None" = None, qpack=None) -> torch.Tensor:
+    """Attention.forward.  pack: the module's MhaPack (bf16 weight cache of the fast path; a throw-away one is built when
+    omitted).  qpack: None, or a QPack prepared for (N, d, T): the fast path also writes y in K2's packed-Q layout (on the
+    staged path the request is dropped and K2 packs q itself)."""
+    return _MHA.apply(x, w_qkv, b_qkv, w_proj, b_proj, int(num_heads), prec_code(prec), torch.is_grad_enabled(), pack, qpack)
+
+
+def mha_group(calls, num_heads: int, prec="fp32"):
+    """Forward of several attention modules in ONE group of launches (no autograd): calls = [(x, w_qkv, b_qkv, w_proj,
+    b_proj, pack)].  Falls back to one call per module when the fast path does not take the configuration, the shapes
+    differ, or a gradient is wanted."""
+    lib = _lib.load()
+    pc = prec_code(prec)
+    xs = [c[0].contiguous() for c in calls]
+    same = all(x.shape == xs[0].shape for x in xs) and 1 < len(calls) <= 4
+    wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for c in calls for t in c[:5])
+    if not same or wants_grad or lib.moma_mha_saved_state(xs[0].shape[0], xs[0].shape[1], int(num_heads), pc) != _lib.MHA_SAVE_LSE:
+        return [mha(c[0], c[1], c[2], c[3], c[4], num_heads, prec, c[5]) for c in calls]
+    items = []
+    for x, c in zip(xs, calls):
+        _mha_check(x, c[1], c[2], c[3], c[4], int(num_heads))
+        holder = c[5] if c[5] is not None else MhaPack()
+        items.append((x, holder.get(c[1], c[3], False), c[2], c[4]))
+    return [o[0] for o in _mha_fast_fwd(items, int(num_heads), False)]
 
 
 # ------------------------------------------------------------------------------------------------

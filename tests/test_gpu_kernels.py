@@ -393,6 +393,61 @@ def test_mha_fused_bwd_peaked(ops, N, d, H):
         assert err < 4e-2, (nm, err)
 
 
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (100, 192, 4), (300, 128, 8)])
+def test_mha_group_equals_single_calls(ops, N, d, H):
+    """Attention.forward_group (the loop's atts_k + atts_queue, helper/loops_moma.py:327-329, as ONE group of three launches)
+    returns bit for bit what the modules return one by one; a weight change is picked up by the bf16 pack."""
+    from moma_amd.MoMA.criterion_moco_att import Attention
+    torch.manual_seed(N + d)
+    mods = [Attention(d, num_heads=H, qkv_bias=True, precision="bf16").cuda() for _ in range(3)]
+    xs = [torch.nn.functional.normalize(torch.randn(N, d, device="cuda")) for _ in range(3)]
+    with torch.no_grad():
+        single = [m(x) for m, x in zip(mods, xs)]
+        group = Attention.forward_group(mods, xs)
+        for a, b in zip(single, group):
+            assert torch.equal(a, b)
+        mods[1].proj.weight.mul_(0.5)                    # in-place update (as optimizer.step does): the pack must follow
+        mods[1].proj.bias.zero_()
+        again = Attention.forward_group(mods, xs)
+        assert torch.equal(again[0], single[0]) and torch.equal(again[2], single[2])
+        
+        ref = mods[1](xs[1])
+        assert torch.equal(again[1], ref) and not torch.equal(ref, single[1])
+
+
+@pytest.mark.parametrize("B,d,H", [(256, 512, 4), (100, 128, 4), (8, 256, 2)])
+def test_k2_takes_the_query_prepacked_by_k1(ops, B, d, H):
+    """atts_q's proj epilogue writes q a second time in the packed bf16 MFMA-operand layout of K2 (moma_mha_module_t.qpack ->
+    moma_infonce_fused_q): K2 then runs no pre-pack launch.  Loss, top-1 and the gradient that reaches x are BIT-identical to
+    the path where K2 packs q itself; an image made from another tensor is ignored."""
+    import copy
+    from moma_amd.MoMA.criterion_moco_att import Attention
+    from moma_amd.MoMA.mem_moco import MoCo
+    torch.manual_seed(B + d)
+    att = Attention(d, num_heads=H, qkv_bias=True, precision="bf16").cuda()
+    mem_a = MoCo(d, K=4096, T=0.15, queue_dtype=torch.bfloat16, precision="bf16").cuda()
+    mem_b = copy.deepcopy(mem_a)
+    x = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
+    k = torch.nn.functional.normalize(x + 0.3 * torch.randn(B, d, device="cuda"))
+    xa = x.clone().requires_grad_(True)
+    la, acc_a = mem_a.forward_fused(att(xa), k)
+    la.backward()
+    xb = x.clone().requires_grad_(True)
+    qp = mem_b.qpack(B, d, x.device)
+    assert qp is not None
+    qb = att(xb, qpack=qp)
+    assert qp.matches(qb, mem_b.T) and not qp.matches(qb.clone(), mem_b.T)
+    lb, acc_b = mem_b.forward_fused(qb, k, qpack=qp)
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(acc_a, acc_b) and torch.equal(xa.grad, xb.grad)
+    assert torch.equal(mem_a.memory, mem_b.memory) and mem_a.index == mem_b.index
+    # a stale image (made from another q) must not be used
+    other = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
+    l1, _ = copy.deepcopy(mem_a).forward_fused(other, k, qpack=qp)
+    l2, _ = copy.deepcopy(mem_a).forward_fused(other, k)
+    assert torch.equal(l1, l2)
+
+
 # ------------------------------------------------------------------------------------------------ ABI
 def test_mha_bitwise_repeatable_gradients(ops):
     """Two forward + backward runs on the same inputs give bit-identical outputs and weight gradients in both policies
@@ -422,7 +477,7 @@ def test_mha_flash_long_sequence_fwd_bwd(ops, N, d, H):
     [H,N,N] is allocated on the GPU side: the saved state is lse [H,N]."""
     from moma_amd import _lib
     assert _lib.load().moma_mha_saved_state(N, d, H, 1) == _lib.MHA_SAVE_LSE
-    assert _lib.load().moma_mha_bwd_workspace_bytes(N, d, H, 1) < (4 * N * d + H * N + 64) * 4 + 256
+    assert _lib.load().moma_mha_bwd_fast_workspace_bytes(N, d, H) < (4 * N * d + H * N + 64) * 4 + 256
     g = torch.Generator().manual_seed(N + d)
     x = torch.nn.functional.normalize(torch.randn(N, d, generator=g))
     bound = 1.0 / np.sqrt(d)
@@ -490,13 +545,13 @@ def test_abi_argument_checks(ops):
     from moma_amd import _lib
     import ctypes as C
     lib = _lib.load()
-    assert lib.moma_version() == _lib.ABI_VERSION == 2
+    assert lib.moma_version() == _lib.ABI_VERSION == 3
     q = torch.zeros(4, 8, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.moma_enqueue(None, C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 0, st) == -1
     assert lib.moma_enqueue(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), 4, 9, 8, 8, 0, st) == -2
     assert lib.moma_enqueue(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 7, st) == -3
-    assert lib.moma_mha_fwd(*([C.c_void_p(q.data_ptr())] * 10), 4, 8, 3, 0, st) == -2
+    assert lib.moma_mha_fwd(*([C.c_void_p(q.data_ptr())] * 9), 4, 8, 3, 0, st) == -2
     assert b"workspace" in lib.moma_error_string(-5)
     with pytest.raises(_lib.MomaHipError):
         ops.enqueue_(torch.zeros(4, 8), torch.zeros(2, 8), 0)      # CPU tensors are refused, no fallback
