@@ -30,14 +30,17 @@ def _install_cpu_standins():
     """Replace the C-ABI wrappers by torch-CPU restatements (reference op order) for host-logic tests."""
     from moma_amd import ops
 
-    def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, prec="fp32"):
+    def mha(x, w_qkv, b_qkv, w_proj, b_proj, num_heads, prec="fp32", pack=None, qpack=None):
         n, c = x.shape
         qkv = F.linear(x, w_qkv, b_qkv).reshape(n, 3, num_heads, c // num_heads).permute(1, 2, 0, 3)
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = ((q @ k.transpose(-2, -1)) * (c // num_heads) ** -0.5).softmax(dim=-1)
         return F.linear((a @ v).transpose(0, 1).reshape(n, c), w_proj, b_proj)
 
-    def infonce_fused(q, k, queue, T, prec="fp32"):
+    def mha_group(calls, num_heads, prec="fp32"):
+        return [mha(*c[:5], num_heads, prec) for c in calls]
+
+    def infonce_fused(q, k, queue, T, prec="fp32", qpack=None):
         logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().clone().t()], dim=1) / T   # pre-enqueue snapshot
         lse = torch.logsumexp(logits, dim=1)
         top1 = (logits[:, 0] >= logits.max(dim=1).values).to(torch.int32)
@@ -61,6 +64,7 @@ def _install_cpu_standins():
                 e.mul_(m).add_(p, alpha=1 - m)
 
     ops.mha, ops.infonce_fused, ops.enqueue_, ops.EmaTable, ops.ema_update_ = mha, infonce_fused, enqueue_, EmaTable, ema_update_
+    ops.mha_group = mha_group
 
 
 def _worker(rank, world, port, shuffle_mode, out):
