@@ -38,11 +38,16 @@ class GraphedInference:
     def _key(self, x, is_feat):
         ac = (torch.is_autocast_enabled(), torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None)
         modes = hash(tuple(m.training for m in self._mods))
-        return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes)
+        # the stream is part of the key: a graph is only ever replayed on the stream that captured it (library workspaces --
+        # hipBLASLt, MIOpen -- belong to the capturing stream; see prime())
+        stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
+        return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes, stream)
 
     def __call__(self, x, is_feat=False, full_feats=False):
-        if full_feats or not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
+        if full_feats:
             return self.module(x, is_feat=is_feat)
+        if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
+            return self._trim(self.module(x, is_feat=is_feat), is_feat)       # one contract whatever path serves the call
         key = self._key(x, is_feat)
         entry = self._graphs.get(key)
         if entry is None:
@@ -60,6 +65,23 @@ class GraphedInference:
         for m in bn_train:                                    # host-side batch counters (see backbones' BatchNorm2d)
             m._nbt_pending += 1
         return self._detach_outputs(out, is_feat)
+
+    def prime(self, x, is_feat=True):
+        """Serve this (shape, autocast, train/eval) variant until it is captured, so that the next call is a replay.  Meant for
+        variants without side effects -- the eval-mode forward that opens every epoch (reference helper/loops_moma.py:227,
+        270-272) -- before a timed region; returns True when the variant is (now) graphed.
+        Call it ON THE STREAM THE REPLAYS WILL RUN ON (the loop's side stream under overlap_teacher): library workspaces
+        (hipBLASLt / MIOpen) belong to the capturing stream, and a replay that runs beside other work of that stream races on
+        them (seen: a variant captured on the main stream and replayed on the side stream next to the student forward
+        returned garbage logits)."""
+        if not (self.enabled and x.is_cuda):
+            return False
+        with torch.no_grad():
+            for _ in range(self.warmup + 1):
+                if self._key(x, is_feat) in self._graphs:
+                    break
+                self(x, is_feat=is_feat)
+            return self._key(x, is_feat) in self._graphs
 
     def _capture(self, key, x, is_feat):
         try:

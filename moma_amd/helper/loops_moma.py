@@ -70,6 +70,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             from .graphs import GraphedInference
             teacher = holder._graphed_teacher = GraphedInference(model_t)
     trace = getattr(opt, "trace", None)
+    step_events = getattr(opt, "step_events", None)     # optional (bench.py): (host time, HIP event) at the end of every step
 
     end = time.time()
     for idx, data in enumerate(train_loader):
@@ -212,6 +213,10 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
 
         batch_time.update(time.time() - end)
         end = time.time()
+        if step_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append((time.perf_counter(), ev))
 
         if idx % opt.print_freq == 0:
             print("Epoch: [{0}][{1}/{2}]\tGPU {3}\tTime: {bt:.3f}\tLoss {loss:.4f}\tAcc@1 {acc:.3f}".format(

@@ -71,7 +71,8 @@ def test_macro_f1_known_answer():
 
 
 def test_graphed_inference_contract_on_cpu_is_eager():
-    """On CPU tensors (or with grad enabled) GraphedInference is a transparent eager call."""
+    """On CPU tensors (or with grad enabled) GraphedInference is an eager call under the SAME return contract as a replay:
+    ([pooled feature], logits); full_feats=True hands out the whole feature list."""
     from moma_amd.helper.graphs import GraphedInference
     from moma_amd.backbones.resnet_cifar import resnet8
     m = resnet8(num_classes=10).eval()
@@ -80,4 +81,6 @@ def test_graphed_inference_contract_on_cpu_is_eager():
     with torch.no_grad():
         feats, logits = g(x, is_feat=True)
         ref_feats, ref_logits = m(x, is_feat=True)
-    assert len(feats) == len(ref_feats) and torch.equal(logits, ref_logits)
+        all_feats, _ = g(x, is_feat=True, full_feats=True)
+    assert len(feats) == 1 and torch.equal(feats[0], ref_feats[-1]) and torch.equal(logits, ref_logits)
+    assert len(all_feats) == len(ref_feats)
