@@ -34,8 +34,10 @@ def fill_attention_(cmo, g, p):
         getattr(cmo, mod).load_state_dict({rest: v}, strict=False)
 
 
-def batches(g, p):
+def batches(g, p, steps=10, B=8):
     gen = torch.Generator().manual_seed(int(g[p + "data_seed"]))
-    images = torch.randn(10, 8, 3, 32, 32, generator=gen)
-    labels = torch.randint(0, 100, (10, 8), generator=gen)
+    images = torch.randn(steps, B, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 100, (steps, B), generator=gen)
+    if p + "images_sum" in g.files:
+        assert abs(images.double().sum().item() - float(g[p + "images_sum"])) < 1e-5, "torch RNG stream changed"
     return images, labels

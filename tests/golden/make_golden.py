@@ -16,6 +16,9 @@ What is captured:
   G7 MoCoAtt     MoMA/mem_moco.py:103-161             cross-attention variants: logits, dq, queue
   G5b step trace helper/loops_moma.py:221-373         the same loop at K = 65536, --head mlp, d in {128, 512}
   G8 shuffle-BN + attention  learning/contrast_trainer.py:135-187   _shuffle_bn_attn, attn in {self_mix, self_nomix}
+  G9 world size 2 learning/contrast_trainer.py:90-187 + MoMA/mem_moco.py:77-100   the reference's Shuffle-BN collectives (image
+                 all_gather, id broadcast, key all_gather) and the global enqueue on TWO gloo ranks: per-rank k / all_k / queue
+  G5c step trace helper/loops_moma.py:221-373         the loop at the BENCHMARK's batch: B = 256, K = 65536, d = 512
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -522,10 +525,203 @@ def g5b_step_trace_big():
     np.savez_compressed(os.path.join(OUT, "g5b_step_trace_big.npz"), **out)
 
 
+def _g9_worker(rank, world, port, path):
+    """One of the two gloo ranks of G9: the reference's _shuffle_bn / _shuffle_bn_attn + MoCo.forward, 3 steps each."""
+    import argparse
+    import torch.distributed as dist
+    _shims()
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from models.resnet import resnet8
+    from MoMA.mem_moco import MoCo
+    from MoMA.criterion_moco_att import CMO
+    from learning.contrast_trainer import ContrastTrainer
+    B, K, d, steps = 6, 40, 32, 3
+    out = {"B": np.array(B), "K": np.array(K), "d": np.array(d), "steps": np.array(steps), "world": np.array(world)}
+    for ci, attn in enumerate(["self", "self_nomix", "self_mix"]):
+        p = f"c{ci}_"
+        opt = argparse.Namespace(head="mlp", s_dim=64, t_dim=64, feat_dim=d, attn=attn, mem="MoCo", nce_k=K, nce_t=0.15,
+                                 local_rank=rank, node_rank=0, ngpus_per_node=world, rank=rank, world_size=world)
+        torch.manual_seed(9900 + ci)                           # identical weights / queue on both ranks
+        model_t = resnet8(num_classes=10)
+        model_t.train()
+        kd = CMO(opt)
+        contrast = MoCo(d, K, 0.15)
+        trainer = ContrastTrainer(opt)
+        trainer.local_group = dist.new_group(list(range(world)))
+        g = torch.Generator().manual_seed(9910 + 10 * ci + rank)   # this rank's images and queries
+        xs = torch.randn(steps, B, 3, 32, 32, generator=g)
+        qs = torch.nn.functional.normalize(torch.randn(steps, B, d, generator=g), dim=2)
+        torch.manual_seed(9950 + 10 * ci + rank)               # host randperm stream (rank 0's permutation is broadcast)
+        if rank == 0:
+            out[p + "attn"] = np.array(attn)
+            for name, t in model_t.state_dict().items():
+                out[p + "t." + name] = t.numpy().copy()
+            for name, t in kd.state_dict().items():
+                out[p + "kd." + name] = t.numpy().copy()
+            out[p + "memory0"] = contrast.memory.numpy().copy()
+            out[p + "perm_seed_rank0"] = np.array(9950 + 10 * ci)
+        r = f"{p}r{rank}_"
+        out[r + "x"] = xs.numpy(); out[r + "q"] = qs.numpy()
+        ks, aks, qouts, logits, idx, mems = [], [], [], [], [], []
+        for t in range(steps):
+            if attn == "self":
+                k, all_k = trainer._shuffle_bn(xs[t], model_t, kd.embed_t)
+                q = qs[t]
+            else:
+                with torch.no_grad():
+                    q, k, all_k = trainer._shuffle_bn_attn(xs[t], model_t, kd.embed_t, kd, qs[t])
+            lg, _lab = contrast(q=q, k=k, all_k=all_k)
+            ks.append(k.detach().numpy().copy()); aks.append(all_k.detach().numpy().copy())
+            qouts.append(q.detach().numpy().copy()); logits.append(lg.detach().numpy().copy())
+            idx.append(contrast.index); mems.append(contrast.memory.numpy().copy())
+        out[r + "k"] = np.stack(ks); out[r + "all_k"] = np.stack(aks); out[r + "q_out"] = np.stack(qouts)
+        out[r + "logits"] = np.stack(logits); out[r + "index"] = np.array(idx, dtype=np.int64); out[r + "memory"] = np.stack(mems)
+        out[r + "t_after.bn1.running_mean"] = model_t.state_dict()["bn1.running_mean"].numpy().copy()
+    np.savez_compressed(f"{path}.rank{rank}.npz", **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def g9_gather_w2():
+    """The reference's W > 1 behaviour that the per-rank build replaces and `--shuffle_bn gather` reproduces
+    (learning/contrast_trainer.py:90-133 and :135-187, MoMA/mem_moco.py:77-100): two gloo ranks, 3 steps per case."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = os.path.join(OUT, "_g9_tmp")
+    mp.spawn(_g9_worker, args=(2, port, path), nprocs=2, join=True)
+    out = {}
+    for r in range(2):
+        f = f"{path}.rank{r}.npz"
+        with np.load(f) as z:
+            for k in z.files:
+                out[k] = z[k]
+        os.remove(f)
+    out["n_cases"] = np.array(3)
+    np.savez_compressed(os.path.join(OUT, "g9_gather_w2.npz"), **out)
+
+
+def g5c_step_trace_b256():
+    """The loop at the benchmark's per-rank batch (B = 256: two 128-row blocks in the one-pass K2, eight key tiles per K1
+    workgroup), K = 65536, --head mlp, d = 512, lr = 0.002, 5 steps.  As in G5b the big tensors (queue, attention weights,
+    images) are re-drawn from seeds by the tests; stored: small weights, per-step loss / loss_kd, pointer, a sample of the
+    enqueued rows and checksums."""
+    import argparse
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import helper.loops_moma as L
+    from models.resnet import resnet8
+    from MoMA.mem_moco import build_mem
+    from MoMA.criterion_moco_att import CMO
+    from learning.contrast_trainer import ContrastTrainer
+    from distiller_zoo import DistillKL
+
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.set_num_threads(8)
+    out = {}
+    K, B, steps, feat_dim, lr = 65536, 256, 5, 512, 0.002
+    opt = argparse.Namespace(
+        distill="moma", head="mlp", feat_dim=feat_dim, attn="self", mem="MoCo", nce_k=K, nce_t=0.15,
+        alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=None, multiprocessing_distributed=True,
+        print_freq=1000, batch_size=B, local_rank=0, node_rank=0, ngpus_per_node=1, rank=0, world_size=1)
+    torch.manual_seed(5400)
+    model_s = resnet8(num_classes=100)
+    model_t = resnet8(num_classes=100)
+    opt.s_dim = opt.t_dim = 64
+    contrast = build_mem(opt)
+    criterion_kd = CMO(opt)
+    gq = torch.Generator().manual_seed(5500)
+    with torch.no_grad():
+        contrast.memory.copy_(torch.nn.functional.normalize(torch.randn(K, feat_dim, generator=gq)))
+    gw = torch.Generator().manual_seed(5600)
+    for name in ("atts_q", "atts_k", "atts_queue"):
+        att = getattr(criterion_kd, name)
+        for lin in (att.qkv, att.proj):
+            b = 1.0 / np.sqrt(lin.in_features)
+            seeded_uniform_(lin.weight, gw, b)
+            seeded_uniform_(lin.bias, gw, b)
+    p = "c0_"
+    out[p + "feat_dim"] = np.array(feat_dim); out[p + "B"] = np.array(B); out[p + "steps"] = np.array(steps)
+    out[p + "seeds"] = np.array([5500, 5600]); out[p + "lr"] = np.array(lr)
+    trainer = ContrastTrainer(opt)
+    trainer.local_group = dist.new_group([0])
+    trainable = nn.ModuleList([model_s, criterion_kd.atts_q, criterion_kd.atts_k, criterion_kd.atts_queue, criterion_kd.embed_s])
+    optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    for name, t in model_s.state_dict().items():
+        out[p + "s." + name] = t.numpy().copy()
+    for name, t in model_t.state_dict().items():
+        out[p + "t." + name] = t.numpy().copy()
+    for name, t in criterion_kd.state_dict().items():
+        if name.startswith("embed_"):
+            out[p + "kd." + name] = t.numpy().copy()
+    out[p + "memory0_sum"] = np.array(contrast.memory.double().sum().item())
+    out[p + "memory0_row7"] = contrast.memory[7].numpy().copy()
+    out[p + "attsq_qkv_w_sum"] = np.array(criterion_kd.atts_q.qkv.weight.double().sum().item())
+    mods = nn.ModuleList([DDP(model_s), model_t])
+    crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(opt.kd_T), criterion_kd])
+    g = torch.Generator().manual_seed(797)
+    images = torch.randn(steps, B, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 100, (steps, B), generator=g)
+    out[p + "data_seed"] = np.array(797)
+    out[p + "images_sum"] = np.array(images.double().sum().item())
+    rec = {"loss": [], "loss_kd": [], "index": []}
+    orig_update = L.AverageMeter.update
+    calls = {"n": 0}
+
+    def upd(self, val, n=1):
+        if calls["n"] % 3 == 0:
+            rec["loss"].append(val)
+        calls["n"] += 1
+        return orig_update(self, val, n)
+
+    orig_cla = ContrastTrainer._compute_loss_accuracy
+
+    def cla(logits, target, criterion):          # helper/loops_moma.py:332-335 -> the step's loss_kd
+        losses, accs = orig_cla(logits=logits, target=target, criterion=criterion)
+        rec["loss_kd"].append(float(losses[0].item()))
+        return losses, accs
+
+    L.AverageMeter.update = upd
+    trainer._compute_loss_accuracy = cla
+    torch.manual_seed(9200)
+    out[p + "loop_seed"] = np.array(9200)
+    try:
+        loader = [(images[i], labels[i]) for i in range(steps)]
+
+        def gen():
+            for it in loader:
+                yield it
+                rec["index"].append(contrast.index)
+
+        class LL:
+            def __len__(self): return steps
+            def __iter__(self): return gen()
+        L.train_distill_moma(1, LL(), mods, crits, trainer, contrast, optimizer, opt)
+    finally:
+        L.AverageMeter.update = orig_update
+    out[p + "loss"] = np.array(rec["loss"], dtype=np.float64)
+    out[p + "loss_kd"] = np.array(rec["loss_kd"], dtype=np.float64)
+    out[p + "index"] = np.array(rec["index"], dtype=np.int64)
+    rows = np.concatenate([np.arange(0, 32), np.arange(B * steps - 32, B * steps)])      # first and last enqueued rows
+    out[p + "memory_rows_ids"] = rows
+    out[p + "memory_rows_final"] = contrast.memory[rows].numpy().copy()
+    out[p + "memory_final_sum"] = np.array(contrast.memory.double().sum().item())
+    out[p + "kd_final.atts_q.proj.weight_8x8"] = criterion_kd.atts_q.proj.weight.detach()[:8, :8].numpy().copy()
+    out[p + "t_final.fc.weight"] = model_t.state_dict()["fc.weight"].numpy().copy()
+    out[p + "s_final.fc.weight"] = model_s.state_dict()["fc.weight"].numpy().copy()
+    out["n_cases"] = np.array(1)
+    np.savez_compressed(os.path.join(OUT, "g5c_step_trace_b256.npz"), **out)
+
+
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b", "g8", "g9", "g5c"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
@@ -535,6 +731,8 @@ if __name__ == "__main__":
     if "g7" in which: g7_mocoatt()
     if "g5b" in which: g5b_step_trace_big()
     if "g8" in which: g8_shuffle_bn_attn()
+    if "g9" in which: g9_gather_w2()
+    if "g5c" in which: g5c_step_trace_b256()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

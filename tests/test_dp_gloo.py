@@ -40,6 +40,9 @@ def _install_cpu_standins():
     def mha_group(calls, num_heads, prec="fp32"):
         return [mha(*c[:5], num_heads, prec) for c in calls]
 
+    def infonce_logits(q, k, queue, T, prec="fp32"):
+        return torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().t()], dim=1) / T
+
     def infonce_fused(q, k, queue, T, prec="fp32", qpack=None):
         logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().clone().t()], dim=1) / T   # pre-enqueue snapshot
         lse = torch.logsumexp(logits, dim=1)
@@ -64,7 +67,7 @@ def _install_cpu_standins():
                 e.mul_(m).add_(p, alpha=1 - m)
 
     ops.mha, ops.infonce_fused, ops.enqueue_, ops.EmaTable, ops.ema_update_ = mha, infonce_fused, enqueue_, EmaTable, ema_update_
-    ops.mha_group = mha_group
+    ops.mha_group, ops.infonce_logits = mha_group, infonce_logits
 
 
 def _worker(rank, world, port, shuffle_mode, out):
@@ -141,3 +144,16 @@ def test_two_rank_data_parallel(tmp_path, shuffle_mode):
         assert r0["all_k_shape"] == (B * world, 32) and r0["k_shape"] == (B, 32)
     # epoch metrics are all-reduced (avg)
     assert r0["red"] == r1["red"] and abs(r0["red"][1] - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
+
+
+def test_gather_mode_matches_reference_at_world_size_2(tmp_path, golden_dir):
+    """n3 pinned to the REFERENCE at W = 2 (G9: learning/contrast_trainer.py:90-187 + MoMA/mem_moco.py:77-100 captured on two gloo
+    ranks): `--shuffle_bn gather` -- image all_gather, id broadcast, teacher on the shuffled local share, key all_gather,
+    un-shuffle, GLOBAL enqueue -- reproduces per-rank k / all_k / logits / queue / pointer for _shuffle_bn and for
+    _shuffle_bn_attn (self_nomix, self_mix).  Host logic on CPU (torch stand-ins for the kernels); the GPU twin of this test
+    runs the HIP kernels underneath."""
+    from tests._g9_worker import compare, run_rank
+    golden = os.path.join(golden_dir, "g9_gather_w2.npz")
+    out = str(tmp_path / "g9")
+    mp.spawn(run_rank, args=(2, _free_port(), golden, "cpu", out), nprocs=2, join=True)
+    compare(golden, out, 2, atol_k=2e-5, atol_logits=2e-4)

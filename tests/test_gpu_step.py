@@ -153,6 +153,80 @@ def test_loop_bf16_policy_matches_reference_trace_big_queue(golden_dir, ci, queu
                                rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("queue_dtype,overlap", [("bf16", True), ("fp32", True), ("bf16", False)])
+def test_loop_bf16_policy_matches_reference_trace_bench_batch(golden_dir, queue_dtype, overlap):
+    """The benchmark's KD configuration at the benchmark's BATCH, tied to the reference at loop level (G5c: B = 256 -- two
+    128-row blocks in the one-pass K2, eight key tiles per K1 workgroup --, K = 65536, --head mlp, d = 512, lr 0.002, 5 steps):
+    bf16 policy (one-pass K2 fed with the query packed by atts_q's proj epilogue, K1 fast path with atts_k + atts_queue as one
+    group, K3, K4), teacher side on the second stream + HIP graphs when overlap is on.  resnet8 backbones stay fp32.
+    North-star tolerance on EVERY step: per-step loss_kd within 1e-3 relative of the reference; pointer exact."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.g5b_util import K_BIG, batches, big_queue, fill_attention_, sd
+    from moma_amd.backbones.resnet_cifar import resnet8
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.distiller_zoo import DistillKL
+
+    torch.backends.cudnn.benchmark = False
+    g = np.load(os.path.join(golden_dir, "g5c_step_trace_b256.npz"))
+    p = "c0_"
+    d, B, steps, lr = int(g[p + "feat_dim"]), int(g[p + "B"]), int(g[p + "steps"]), float(g[p + "lr"])
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K_BIG, nce_t=0.15,
+                             alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False,
+                             print_freq=1000, batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16",
+                             queue_dtype=queue_dtype, moma_fused=True, trace=[], overlap_teacher=overlap,
+                             graph_teacher=overlap)
+    dev = torch.device("cuda", 0)
+    ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
+    ms.load_state_dict(sd(g, p + "s.")); mt.load_state_dict(sd(g, p + "t."))
+    contrast = build_mem(opt)
+    contrast.memory.copy_(big_queue(g, p, d).to(contrast.memory.dtype))
+    kd = CMO(opt)
+    fill_attention_(kd, g, p)
+    ms, mt, contrast, kd = ms.to(dev), mt.to(dev), contrast.to(dev), kd.to(dev)
+    trainer = ContrastTrainer(opt)
+    trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+    optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    mods = nn.ModuleList([ms, mt])
+    crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(opt.kd_T), kd])
+    images, labels = batches(g, p, steps, B)
+    torch.manual_seed(int(g[p + "loop_seed"]))
+    train_distill_moma(1, [(images[i], labels[i]) for i in range(steps)], mods, crits, trainer, contrast, optimizer, opt)
+    losses = np.array([float(t[0]) for t in opt.trace])
+    kds = np.array([float(t[2]) for t in opt.trace])
+    assert [t[1] for t in opt.trace] == [int(v) for v in g[p + "index"]]
+    ref_kd, ref_loss = g[p + "loss_kd"], g[p + "loss"]
+    print("loss_kd rel err:", (np.abs(kds - ref_kd) / np.abs(ref_kd)).round(6), " total |err|:", np.abs(losses - ref_loss).round(5))
+    np.testing.assert_allclose(kds, ref_kd, rtol=1e-3, atol=0)           # north star, every step
+    np.testing.assert_allclose(losses, ref_loss, rtol=1e-3, atol=0)
+    ids = torch.from_numpy(g[p + "memory_rows_ids"]).to(dev)
+    rows = contrast.memory[ids].float().cpu().numpy()
+    ref_rows = g[p + "memory_rows_final"]
+    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
+    np.testing.assert_allclose(kd.atts_q.proj.weight.detach()[:8, :8].cpu().numpy(), g[p + "kd_final.atts_q.proj.weight_8x8"],
+                               rtol=0, atol=2e-3)
+
+
+def test_gather_mode_matches_reference_at_world_size_2_on_gpu(golden_dir, tmp_path):
+    """n3 on the hardware path: two processes on ONE GPU (gloo carries the collectives; RCCL refuses two ranks on one device),
+    `--shuffle_bn gather` with the HIP kernels underneath (K1 staged fp32 path, K2 logits, K3 enqueue), against the vectors the
+    REFERENCE produced on two ranks (G9): pointer exact, enqueue order exact (same rows in the same slots on both ranks),
+    keys / logits within fp32 kernel tolerance.  The CPU twin (tests/test_dp_gloo.py) checks the host logic alone."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.multiprocessing as mp
+    from tests._g9_worker import compare, run_rank
+    golden = os.path.join(golden_dir, "g9_gather_w2.npz")
+    out = str(tmp_path / "g9")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(run_rank, args=(2, port, golden, "cuda", out), nprocs=2, join=True)
+    compare(golden, out, 2, atol_k=2e-4, atol_logits=2e-3)
+
+
 def test_shuffle_bn_gather_mode_single_rank_equals_per_rank(golden_dir):
     """`--shuffle_bn gather` (the reference's collectives C3-C5: image all_gather, id broadcast, key all_gather; reference
     learning/contrast_trainer.py:90-133) on a one-rank RCCL process group must reproduce the per-rank mode bit for bit:

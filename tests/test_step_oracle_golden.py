@@ -94,6 +94,35 @@ def test_step_trace_big_queue_matches_reference(golden_dir):
                                rtol=1e-4, atol=1e-6)
 
 
+def test_step_trace_bench_batch_matches_reference(golden_dir):
+    """The loop at the benchmark's per-rank batch (G5c: B = 256, K = 65536, --head mlp, d = 512, lr 0.002, 5 steps): the oracle
+    against the reference's own per-step total loss and loss_kd, the pointer and a sample of the enqueued rows."""
+    from tests.g5b_util import K_BIG, batches, big_queue, fill_attention_, sd
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "g5c_step_trace_b256.npz"))
+    p = "c0_"
+    d, B, steps = int(g[p + "feat_dim"]), int(g[p + "B"]), int(g[p + "steps"])
+    ms, mt = resnet8(num_classes=100), resnet8(num_classes=100)
+    ms.load_state_dict(sd(g, p + "s.")); mt.load_state_dict(sd(g, p + "t."))
+    cmo = OracleCMO("mlp", 64, 64, d)
+    fill_attention_(cmo, g, p)
+    contrast = OracleMoCo(d, K_BIG, 0.15)
+    contrast.memory.copy_(big_queue(g, p, d))
+    run = StepOracle(ms, mt, cmo, contrast, head="mlp", lr=float(g[p + "lr"]))
+    images, labels = batches(g, p, steps, B)
+    torch.manual_seed(int(g[p + "loop_seed"]))
+    losses, kds, idxs = [], [], []
+    run.start_epoch()
+    for i in range(steps):
+        loss, _, kd = run.step(images[i], labels[i])
+        losses.append(loss); kds.append(kd); idxs.append(contrast.index)
+    assert idxs == [int(v) for v in g[p + "index"]]
+    np.testing.assert_allclose(losses, g[p + "loss"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(kds, g[p + "loss_kd"], rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(contrast.memory[torch.from_numpy(g[p + "memory_rows_ids"])].numpy(), g[p + "memory_rows_final"],
+                               rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("ci", [0, 1, 2])
 def test_shuffle_bn_attn_oracle_matches_reference(golden_dir, ci):
     """oracle/step_oracle.py:shuffle_bn_attn against the vectors captured from the reference's _shuffle_bn_attn (G8)."""
