@@ -198,6 +198,12 @@ class ContrastTrainer(BaseTrainer):
         module that took no part in this step's graph), average, and scatter back into the .grad tensors."""
         if getattr(self, "_gs_params", None) is None:
             return
+        if self._gs_work is not None and self._gs_seen != self._gs_expect:
+            # the hooks launched the reduce when the EXPECTED number of gradients had arrived, and more arrived after it (another
+            # branch of the criterion took part in this backward, a head was un-frozen): the flat buffer in flight misses
+            # them.  Drop it -- the .grad tensors are still the local, un-reduced ones -- and reduce everything, blocking.
+            self._gs_work.wait()
+            self._gs_work, self._gs_flat = None, None
         if self._gs_work is None:
             if self._gs_seen > 0:
                 self._gs_expect = self._gs_seen                 # from the next step on the hooks launch it early

@@ -203,6 +203,37 @@ def _rank_state_path(folder, rank):
     return os.path.join(folder, "ckpt_last_rank{}.pth".format(int(rank)))
 
 
+def _atomic_save(obj, path):
+    """torch.save through a temporary name + rename: a job killed mid-write leaves the previous file, never a truncated one."""
+    tmp = "{}.tmp{}".format(path, os.getpid())
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+def _load_rank_state(folder, rank, epoch, device):
+    """This rank's queue / pointer / RNG state, or None when the file is absent, unreadable or belongs to ANOTHER epoch than
+    the shared checkpoint (a job killed between the two writes, stale files of an earlier run in the same folder): the caller
+    then falls back to the shared file's queue and leaves the RNG streams alone."""
+    mine = _rank_state_path(folder, rank)
+    if not os.path.isfile(mine):
+        return None
+    try:
+        rs = torch.load(mine, map_location=device, weights_only=False)
+    except Exception as e:                                  # truncated / foreign file
+        print("[moma] per-rank checkpoint {} unreadable ({}: {}); using the shared queue state".format(mine, type(e).__name__, e))
+        return None
+    if rs.get("epoch") != epoch:
+        print("[moma] per-rank checkpoint {} is from epoch {} but the shared checkpoint from epoch {}: ignored "
+              "(queue / pointer from the shared file, RNG streams not restored)".format(mine, rs.get("epoch"), epoch))
+        return None
+    return rs
+
+
+# The product needs a GPU (no CPU path exists for the kernels).  Host-logic tests that replace the kernel wrappers by
+# stand-ins set this module attribute to False; nothing in the product or its CLI does.
+_REQUIRE_GPU = True
+
+
 def _get_rng_state(device):
     return {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
             "cuda": torch.cuda.get_rng_state(device) if device.type == "cuda" else None}
@@ -222,10 +253,7 @@ def main_worker(gpu, ngpus_per_node, opt):
     # node rank: torchrun exports GROUP_RANK (NODE_RANK is the older launcher's name); single node -> 0
     opt.rank = int(os.environ.get("GROUP_RANK", os.environ.get("NODE_RANK", 0)))
     opt.dist_backend = os.environ.get("MOMA_DIST_BACKEND", "nccl")      # 'nccl' = RCCL on ROCm (reference :232)
-    # MOMA_HOST_TEST_CPU=1 lets the HOST logic (process group, DDP wrap, epoch loop, checkpoints) run in CPU-only tests that
-    # replace the kernel wrappers by stand-ins; the product itself has no CPU path: without stand-ins the first kernel call raises
-    host_test = os.environ.get("MOMA_HOST_TEST_CPU") == "1"
-    if not torch.cuda.is_available() and not host_test:
+    if not torch.cuda.is_available() and _REQUIRE_GPU:
         raise RuntimeError("train_student_moma: no GPU visible. The MoMA hot path is a HIP library for gfx950 "
                            "and has no CPU fallback.")
     trainer = ContrastTrainer(opt)
@@ -268,8 +296,7 @@ def main_worker(gpu, ngpus_per_node, opt):
         optimizer.load_state_dict(ck["optimizer"])
         # per-rank state (the queue and its pointer are per rank in the default per_rank mode, and so are the RNG streams)
         # sits next to the shared file; a run resumed on fewer / other ranks falls back to rank 0's queue
-        mine = _rank_state_path(os.path.dirname(opt.resume), opt.rank)
-        rs = torch.load(mine, map_location=device, weights_only=False) if os.path.isfile(mine) else None
+        rs = _load_rank_state(os.path.dirname(opt.resume), opt.rank, ck["epoch"], device)
         if contrast is not None:
             qstate = (rs or {}).get("contrast") or ck.get("contrast")
             if qstate is not None:
@@ -310,26 +337,29 @@ def main_worker(gpu, ngpus_per_node, opt):
                 best_acc = val_acc
                 state.update(best_acc=best_acc, best_acc_epoch=epoch)
                 print("saving the best acc model!")
-                torch.save(state, os.path.join(opt.save_folder, "net_best_acc.pth"))
+                _atomic_save(state, os.path.join(opt.save_folder, "net_best_acc.pth"))
             if val_f1 > best_f1:
                 best_f1 = val_f1
                 state.update(best_f1=best_f1, best_f1_epoch=epoch)
                 print("saving the best f1 model!")
-                torch.save(state, os.path.join(opt.save_folder, "net_best_f1.pth"))
+                _atomic_save(state, os.path.join(opt.save_folder, "net_best_f1.pth"))
             metrics = {"val_cf": val_stat["conf_mat"].tolist(), "val_loss": val_loss, "val_acc": val_acc}
             if test_stat is not None:
                 metrics.update(test_cf=test_stat["conf_mat"].tolist(), test_loss=test_loss, test_acc=test_acc)
             update_dict_to_json(epoch, metrics, os.path.join(opt.save_folder, "stat.json"))
             # full training state (the reference saves the student only): shared part by the main rank ...
-            torch.save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
-                        "criterion_kd": criterion_list[2].state_dict(),
-                        "contrast": contrast.state_dict() if contrast is not None else None,
-                        "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1},
-                       os.path.join(opt.save_folder, "ckpt_last.pth"))
-        # ... and the per-rank part (queue + pointer of THIS rank, RNG streams) by every rank
+            _atomic_save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
+                          "criterion_kd": criterion_list[2].state_dict(),
+                          "contrast": contrast.state_dict() if contrast is not None else None,
+                          "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1},
+                         os.path.join(opt.save_folder, "ckpt_last.pth"))
+        # ... and the per-rank part (queue + pointer of THIS rank, RNG streams) by every rank; both carry the epoch and a
+        # resume only pairs files of the same epoch (_load_rank_state)
         os.makedirs(opt.save_folder, exist_ok=True)
-        torch.save({"epoch": epoch, "contrast": contrast.state_dict() if contrast is not None else None,
-                    "rng": _get_rng_state(device)}, _rank_state_path(opt.save_folder, opt.rank))
+        _atomic_save({"epoch": epoch, "contrast": contrast.state_dict() if contrast is not None else None,
+                      "rng": _get_rng_state(device)}, _rank_state_path(opt.save_folder, opt.rank))
+        if opt.multiprocessing_distributed and torch.distributed.is_initialized():
+            torch.distributed.barrier()                         # no rank starts the next epoch before every file of this one exists
     if is_main:
         print("best accuracy:", best_acc)
         save_state = {k: v for k, v in vars(opt).items() if not k.startswith("_") and k != "trace"}

@@ -8,7 +8,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["MOMA_HOST_TEST_CPU"] = "1"
 os.environ["MOMA_DIST_BACKEND"] = "gloo"
 
 import torch  # noqa: E402
@@ -19,6 +18,8 @@ from tests.test_dp_gloo import _install_cpu_standins  # noqa: E402
 torch.set_num_threads(1)
 _install_cpu_standins()
 from moma_amd import train_student_moma as T  # noqa: E402
+
+T._REQUIRE_GPU = False                                   # host-logic test: the kernel wrappers are stand-ins here
 from moma_amd.learning.base_trainer import BaseTrainer  # noqa: E402
 
 out_dir = sys.argv[1]
@@ -38,5 +39,5 @@ BaseTrainer.init_ddp_environment = spy
 T.main(["--distill", "moma", "--model_s", "resnet8", "--model_t", "resnet8", "--dataset", "cifar100", "--n_cls", "4",
         "--batch_size", "4", "--epochs", "1", "--steps_per_epoch", "3", "--nce_k", "64", "--head", "mlp", "--feat_dim", "32",
         "-c", "1", "-d", "1", "-b", "1", "--moma_prec", "fp32", "--print_freq", "1", "--save_root", out_dir,
-        "--no_graph_teacher", "--no_overlap_teacher"])
+        "--no_graph_teacher", "--no_overlap_teacher"] + sys.argv[2:])
 json.dump(seen, open(os.path.join(out_dir, f"seen_rank{os.environ['RANK']}.json"), "w"))

@@ -157,3 +157,46 @@ def test_gather_mode_matches_reference_at_world_size_2(tmp_path, golden_dir):
     out = str(tmp_path / "g9")
     mp.spawn(run_rank, args=(2, _free_port(), golden, "cpu", out), nprocs=2, join=True)
     compare(golden, out, 2, atol_k=2e-5, atol_logits=2e-4)
+
+
+def _grad_sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    torch.manual_seed(0)
+    layers = nn.ModuleList([nn.Linear(4, 4) for _ in range(4)])          # the 4th never takes part (like atts_k: grad stays None)
+    params = list(layers.parameters())
+    trainer = ContrastTrainer(argparse.Namespace(rank=rank, local_rank=rank, world_size=world))
+    trainer.attach_grad_sync(params)
+    g = torch.Generator().manual_seed(10 + rank)
+    ok = True
+    # which layers take part per step: the count of gradient-receiving parameters goes 4 -> 6 (MORE than the hooks learnt) ->
+    # 2 (fewer) -> 6 -> 6 (steady: launched from the hooks)
+    for step, used in enumerate([(0, 1), (0, 1, 2), (0,), (0, 1, 2), (0, 1, 2)]):
+        for p in params:
+            p.grad = None
+        x = torch.randn(3, 4, generator=g)
+        sum(layers[i](x).pow(2).sum() for i in used).backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        trainer.finish_grad_sync()
+        for p, l in zip(params, local):
+            if l is None:
+                ok = ok and p.grad is None
+                continue
+            ref = l.clone()
+            dist.all_reduce(ref)
+            ok = ok and torch.allclose(p.grad, ref / world, rtol=0, atol=1e-7)
+    torch.save({"ok": ok, "expect": trainer._gs_expect}, f"{out}.rank{rank}")
+    dist.destroy_process_group()
+
+
+def test_criterion_grad_sync_survives_a_changing_gradient_set(tmp_path):
+    """the hook-launched flat all-reduce of the criterion gradients learns how many gradients a backward
+    produces on the first step; a later backward that produces MORE must not leave the late ones un-reduced (and fewer
+    must not hang): every step's gradients equal the rank average, whatever the set."""
+    out = str(tmp_path / "gs")
+    mp.spawn(_grad_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(f"{out}.rank{r}")
+        assert res["ok"] and res["expect"] == 6

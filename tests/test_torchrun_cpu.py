@@ -41,3 +41,19 @@ def test_main_torchrun_branch_two_ranks_gloo(tmp_path):
     assert not torch.equal(q0["memory"], q1["memory"])                                # different data shard per rank
     shared = torch.load(ck["ckpt_last.pth"], weights_only=False)
     assert shared["epoch"] == 1 and "model_t" in shared and "criterion_kd" in shared
+
+
+    # ---- resume: rank 1's per-rank file is made to look like another epoch's (a job killed between the two writes / stale
+    # files in the folder): it must be ignored -- queue from the shared file, no RNG restore -- while rank 0's is used
+    rs = torch.load(ck["ckpt_last_rank1.pth"], weights_only=False)
+    rs["epoch"] = 7
+    torch.save(rs, ck["ckpt_last_rank1.pth"])
+    cmd2 = cmd[:-1] + [str(tmp_path), "--resume", ck["ckpt_last.pth"], "--epochs", "2"]
+    cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
+    r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    assert "is from epoch 7 but the shared checkpoint from epoch 1: ignored" in r2.stdout
+    assert "per-rank state found" in r2.stdout and "per-rank state absent" in r2.stdout
+    again = torch.load(ck["ckpt_last_rank1.pth"], weights_only=False)
+    assert again["epoch"] == 2 and again["contrast"]["_extra_state"]["index"] == 24      # continued from the shared pointer (12)
+    assert not any(f.endswith(".pth") is False and ".tmp" in f for _, _, fs in os.walk(tmp_path) for f in fs)   # no leftovers
