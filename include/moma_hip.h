@@ -138,6 +138,27 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
                          void* workspace, size_t workspace_bytes, int qdtype, int prec,
                          moma_stream_t stream, void* ev_begin, void* ev_end);
 
+/* Several InfoNCE terms over queues of the same shape in ONE sweep -- replaces the 2 / 4 `_compute_logit` calls + CrossEntropy of
+ * the dual-queue memories MoCoST.forward / MoCoSSTT.forward (MoMA/mem_moco.py:165-253):
+ *     (q, k, memory_s), (q, k_t, memory_t) [, (q_t, k, memory_s), (q_t, k_t, memory_t)]
+ * One pre-pack launch over the distinct q pointers, ONE launch of the one-pass kernel over every (term, query tile, key chunk) --
+ * sized to one workgroup per compute unit over all terms, the queues streamed back to back --, one combine launch: 3 launches
+ * for any number of terms (<= 4).  Per term the outputs of moma_infonce_fused; dq either for every term or for none (a query
+ * shared by two terms gets two dq buffers: the caller adds them).  bf16 policy + bf16 queues + d in {128, 256, 384, 512} only:
+ * moma_infonce_fused_multi_workspace_bytes() returns 0 otherwise and the caller makes one moma_infonce_fused call per term. */
+typedef struct moma_infonce_term {
+    const float* q;        /* [B,d] fp32  */
+    const float* k;        /* [B,d] fp32  */
+    const void* queue;     /* [K,d] bf16  */
+    float* loss_rows;      /* [B] out     */
+    float* lse;            /* [B] out     */
+    int32_t* top1;         /* [B] out     */
+    float* dq;             /* [B,d] out or NULL */
+} moma_infonce_term_t;
+size_t moma_infonce_fused_multi_workspace_bytes(int n_terms, int B, int d, int K, int qdtype, int prec);
+int moma_infonce_fused_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T,
+                             void* workspace, size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K1  batch-token multi-head attention -- replaces Attention.forward
  *     (MoMA/criterion_moco_att.py:153-167) and its autograd backward.

@@ -228,10 +228,11 @@ class MoCoST(_DualQueue):
         return logits_ss, logits_st, labels
 
     def forward_fused(self, q, k, k_t, all_k=None, all_k_t=None):
-        """-> ((loss_ss, loss_st), (acc_ss, acc_st)): each InfoNCE term in one pass over its queue."""
+        """-> ((loss_ss, loss_st), (acc_ss, acc_st)): both InfoNCE terms in ONE sweep over the two queues
+        (ops.infonce_fused_multi: one pre-pack of q, one launch streaming memory_s then memory_t, one combine)."""
         k, k_t = k.detach(), k_t.detach()
-        l_ss, _, t_ss = ops.infonce_fused(q, k, self.memory_s, self.T, self.precision)
-        l_st, _, t_st = ops.infonce_fused(q, k_t, self.memory_t, self.T, self.precision)
+        (l_ss, _, t_ss), (l_st, _, t_st) = ops.infonce_fused_multi(
+            [(q, k, self.memory_s), (q, k_t, self.memory_t)], self.T, self.precision)
         self._enqueue_both(k, k_t, all_k, all_k_t)
         acc = lambda t: t.float().mean(0, keepdim=True) * 100.0
         return (l_ss.mean(), l_st.mean()), (acc(t_ss), acc(t_st))
@@ -253,6 +254,17 @@ class MoCoSSTT(_DualQueue):
         if q_t is not None:
             return logits_ss, logits_st, logits_ts, logits_tt, labels
         return logits_ss, logits_st, labels
+
+    def forward_fused(self, q, k, q_t=None, k_t=None, all_k=None, all_k_t=None):
+        """-> (losses, accuracies) in the reference's order (ss, st[, ts, tt]): the 2 / 4 InfoNCE terms of :230-238 in ONE sweep
+        over the two queues (two query sets packed by one launch), without materialising any [B,K+1] logits."""
+        k, k_t = k.detach(), k_t.detach()
+        terms = [(q, k, self.memory_s), (q, k_t, self.memory_t)]
+        if q_t is not None:
+            terms += [(q_t, k, self.memory_s), (q_t, k_t, self.memory_t)]
+        res = ops.infonce_fused_multi(terms, self.T, self.precision)
+        self._enqueue_both(k, k_t, all_k, all_k_t)
+        return tuple(r[0].mean() for r in res), tuple(r[2].float().mean(0, keepdim=True) * 100.0 for r in res)
 
 
 def build_mem(opt):

@@ -39,6 +39,8 @@ SIGNATURES = {
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
     "moma_infonce_qpack_bytes": (_z, [_i, _i]),
     "moma_infonce_fused_q": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
+    "moma_infonce_fused_multi_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "moma_infonce_fused_multi": (_i, [_p, _i, _i, _i, _i, _f, _p, _z, _i, _i, _p]),
     "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "moma_mha_saved_state": (_i, [_i, _i, _i, _i]),
     "moma_mha_pack_bytes": (_z, [_i]),
@@ -60,6 +62,11 @@ SIGNATURES = {
     "moma_mha_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
 }
 
+
+
+class InfoNCETerm(C.Structure):
+    """moma_infonce_term_t of include/moma_hip.h (one term of a moma_infonce_fused_multi call)."""
+    _fields_ = [("q", _p), ("k", _p), ("queue", _p), ("loss_rows", _p), ("lse", _p), ("top1", _p), ("dq", _p)]
 
 
 class MhaModule(C.Structure):

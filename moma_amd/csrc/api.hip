@@ -177,6 +177,27 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     return MOMA_OK;
 }
 
+size_t moma_infonce_fused_multi_workspace_bytes(int n_terms, int B, int d, int K, int qdtype, int prec) {
+    return infonce_multi_supported(n_terms, B, d, K, qdtype, prec) ? infonce_multi_workspace_bytes(n_terms, B, d, K) : 0;
+}
+
+int moma_infonce_fused_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* workspace,
+                             size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream) {
+    if (!terms || !workspace) return MOMA_E_NULL;
+    if (n_terms < 1 || n_terms > 4 || B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
+    if (!infonce_multi_supported(n_terms, B, d, K, qdtype, prec)) return MOMA_E_UNSUPPORTED;
+    for (int i = 0; i < n_terms; ++i) {
+        const moma_infonce_term_t& t = terms[i];
+        if (!t.q || !t.k || !t.queue || !t.loss_rows || !t.lse || !t.top1) return MOMA_E_NULL;
+        if ((t.dq != nullptr) != (terms[0].dq != nullptr)) return MOMA_E_UNSUPPORTED;     // every term with dq, or none
+        if (misaligned(t.q, 16) || misaligned(t.k, 4) || misaligned(t.queue, 16)) return MOMA_E_ALIGN;
+    }
+    if (workspace_bytes < infonce_multi_workspace_bytes(n_terms, B, d, K)) return MOMA_E_WORKSPACE;
+    if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
+    return hip_rc(launch_infonce_multi(terms, n_terms, B, d, K, inv_T, workspace, (hipStream_t)stream));
+}
+
 int moma_mha_saved_state(int N, int d, int H, int prec) {
     if (N <= 0 || d <= 0 || H <= 0 || d % H != 0 || bad_prec(prec)) return MOMA_E_SHAPE;
     return mha_fast_supported(N, d, H, prec) ? MOMA_MHA_SAVE_LSE : MOMA_MHA_SAVE_PROBS;

@@ -92,6 +92,10 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                                 hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
                                 const void* q_packed = nullptr);
 size_t infonce_qpack_bytes(int B, int d);
+bool infonce_multi_supported(int n_terms, int B, int d, int K, int qdtype, int prec);
+size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K);
+hipError_t launch_infonce_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* ws,
+                                hipStream_t st);
 
 // ---- k1_fast.hip (batch-token attention, bf16 fast path) -------------------------------------------
 bool mha_fast_supported(int N, int d, int H, int prec);

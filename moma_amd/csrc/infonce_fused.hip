@@ -1429,16 +1429,16 @@ __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __
 // Scalars: 32 threads per row.  dq: the 256 threads are 8 chunk-groups x 32 columns, one 16-B load (8 rows of a column) per
 // thread and chunk; the chunk-groups are summed through LDS in a fixed order (bitwise reproducible).
 constexpr int COMBINE_MAX_CHUNKS = 1024;
-__global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                               int B, int D, float inv_T, int nchunk, int Bpad,
-                                                               const uint4* __restrict__ o_part,
-                                                               const float* __restrict__ m_part,
-                                                               const float* __restrict__ l_part,
-                                                               const float* __restrict__ x_part,
-                                                               float* __restrict__ loss_rows, float* __restrict__ lse_out,
-                                                               int32_t* __restrict__ top1, float* __restrict__ dq,
-                                                               long slab_stride, int cg, int tpb,
-                                                               const float* __restrict__ ref_part) {
+__device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q, const float* __restrict__ k,
+                                                     int B, int D, float inv_T, int nchunk, int Bpad,
+                                                     const uint4* __restrict__ o_part,
+                                                     const float* __restrict__ m_part,
+                                                     const float* __restrict__ l_part,
+                                                     const float* __restrict__ x_part,
+                                                     float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                     int32_t* __restrict__ top1, float* __restrict__ dq,
+                                                     long slab_stride, int cg, int tpb,
+                                                     const float* __restrict__ ref_part) {
     // ref_part: per (chunk, row) reference of the O partials when it is not m_part (wide rows: the integer references of pass 1)
     // tpb: column tiles per block (grid.y = ceil(D/32 / tpb)).  Every block repeats the row statistics of its 8 rows: 16x at
     // d = 512 with tpb = 1 (cheap); wide rows take 4 tiles per block (10x instead of 40x at d = 1280) in the same single launch.
@@ -1603,16 +1603,111 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               int B, int D, float inv_T, int nchunk, int Bpad,
+                                                               const uint4* __restrict__ o_part,
+                                                               const float* __restrict__ m_part,
+                                                               const float* __restrict__ l_part,
+                                                               const float* __restrict__ x_part,
+                                                               float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                               int32_t* __restrict__ top1, float* __restrict__ dq,
+                                                               long slab_stride, int cg, int tpb,
+                                                               const float* __restrict__ ref_part) {
+    infonce_combine_body(q, k, B, D, inv_T, nchunk, Bpad, o_part, m_part, l_part, x_part, loss_rows, lse_out, top1, dq, slab_stride,
+                         cg, tpb, ref_part);
+}
+
+// ---- several InfoNCE terms in ONE sweep (the dual-queue memories MoCoST / MoCoSSTT, reference MoMA/mem_moco.py:165-253:
+// (q, k, memory_s), (q, k_t, memory_t) [, (q_t, k, memory_s), (q_t, k_t, memory_t)]): one pre-pack launch over the distinct
+// query sets, one launch of the one-pass kernel whose grid covers every (term, query tile, key chunk) -- sized to one
+// workgroup per compute unit over ALL terms, so the queues are streamed back to back by the same launch --, one combine.
+constexpr int MULTI_MAX_TERMS = 4;
+struct MultiTerm {
+    const float* q;
+    const float* k;
+    const bf16_raw* queue;
+    float* loss_rows;
+    float* lse;
+    int32_t* top1;
+    float* dq;
+    int qset;                 // index of the term's query among the distinct query sets
+};
+struct MultiArgs {
+    MultiTerm t[MULTI_MAX_TERMS];
+    const float* qsets[MULTI_MAX_TERMS];
+    int n, nq;
+};
+// (a run-time index into a by-value kernel argument sends the struct to scratch: select with compile-time indices)
+__device__ __forceinline__ MultiTerm pick_term(const MultiArgs& a, int term) {
+    MultiTerm t = a.t[0];
+#pragma unroll
+    for (int i = 1; i < MULTI_MAX_TERMS; ++i)
+        if (term == i) t = a.t[i];
+    return t;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void infonce_qpack_multi_kernel(MultiArgs a, int B, float scale_log2, uint4* __restrict__ qpack,
+                                                                  int n_row_tiles, long qset_stride) {
+    constexpr int KS = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);          // (row tile, k-step)
+    if (item >= n_row_tiles * KS) return;
+    const float* q = a.qsets[0];
+#pragma unroll
+    for (int i = 1; i < MULTI_MAX_TERMS; ++i)
+        if ((int)blockIdx.y == i) q = a.qsets[i];
+    const int rt = item / KS, ks = item % KS;
+    const int row = rt * 32 + (lane & 31), h = lane >> 5;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+    if (row < B) {
+        const float* qp = q + (long)row * D + 16 * ks + 8 * h;
+        x = *reinterpret_cast<const float4*>(qp);
+        y = *reinterpret_cast<const float4*>(qp + 4);
+    }
+    const bf16x8 f = bf16x8{(__bf16)(x.x * scale_log2), (__bf16)(x.y * scale_log2), (__bf16)(x.z * scale_log2),
+                            (__bf16)(x.w * scale_log2), (__bf16)(y.x * scale_log2), (__bf16)(y.y * scale_log2),
+                            (__bf16)(y.z * scale_log2), (__bf16)(y.w * scale_log2)};
+    qpack[(long)blockIdx.y * qset_stride + (long)item * 64 + lane] = __builtin_bit_cast(uint4, f);
+}
+
+template <int D, bool WITH_DQ>
+__global__ __launch_bounds__(256, 1) void infonce_flash_multi_kernel(MultiArgs a, const uint4* __restrict__ qpack, long qset_stride,
+                                                                     int B, int K, int nbt, int nchunk, int tiles_per_chunk, int Bpad,
+                                                                     uint4* __restrict__ o_part, long o_term_stride,
+                                                                     float* __restrict__ m_part, float* __restrict__ l_part,
+                                                                     float* __restrict__ x_part, long term_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int per = nbt * nchunk;
+    const int term = blockIdx.x / per, id = blockIdx.x - term * per;
+    const MultiTerm t = pick_term(a, term);
+    infonce_flash_body<D, WITH_DQ>(id, smem, qpack + t.qset * qset_stride, t.queue, B, K, nbt, nchunk, tiles_per_chunk, Bpad,
+                                   o_part + term * o_term_stride, m_part + term * term_rows, l_part + term * term_rows,
+                                   x_part + term * term_rows);
+}
+
+__global__ __launch_bounds__(256) void infonce_combine_multi_kernel(MultiArgs a, int B, int D, float inv_T, int nchunk, int Bpad,
+                                                                     const uint4* __restrict__ o_part, long o_term_stride,
+                                                                     const float* __restrict__ m_part,
+                                                                     const float* __restrict__ l_part,
+                                                                     const float* __restrict__ x_part, long term_rows) {
+    const int term = blockIdx.z;
+    const MultiTerm t = pick_term(a, term);
+    infonce_combine_body(t.q, t.k, B, D, inv_T, nchunk, Bpad, o_part + term * o_term_stride, m_part + term * term_rows,
+                         l_part + term * term_rows, x_part + term * term_rows, t.loss_rows, t.lse, t.top1, t.dq, 0L, 1, 1,
+                         m_part + term * term_rows);
+}
+
 struct FlashPlan {
     int nbt, nchunk, tiles_per_chunk, Bpad;
 };
 
-FlashPlan plan(int B, int K) {
+FlashPlan plan(int B, int K, int nterms = 1) {
     FlashPlan p;
     p.nbt = (B + QROWS_WG - 1) / QROWS_WG;
     p.Bpad = p.nbt * QROWS_WG;
     const int ntiles = (K + KT - 1) / KT;
-    int want = 256 / p.nbt;                    // ~1 workgroup per CU
+    int want = 256 / (p.nbt * nterms);         // ~1 workgroup per CU over all terms
     if (want < 8) want = 8;
     if (want > 1024) want = 1024;
     want = (want / 8) * 8;
@@ -1653,6 +1748,8 @@ void set_lds_attrs() {
 #define MOMA_SET_LDS(DD)                                                                                                        \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);     \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);    \
+    (void)hipFuncSetAttribute((const void*)infonce_flash_multi_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);   \
+    (void)hipFuncSetAttribute((const void*)infonce_flash_multi_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);  \
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);         \
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
     MOMA_SET_LDS(512); MOMA_SET_LDS(384); MOMA_SET_LDS(256); MOMA_SET_LDS(128);
@@ -1798,6 +1895,68 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
                        p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
+    return hipGetLastError();
+}
+
+size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K) {
+    const FlashPlan p = plan(B, K, n_terms);
+    const size_t rows = (size_t)p.nchunk * p.Bpad;
+    return (size_t)n_terms * (rows * d * 2 + 3 * rows * sizeof(float)) + (size_t)n_terms * p.Bpad * d * 2 + 2048;
+}
+
+bool infonce_multi_supported(int n_terms, int B, int d, int K, int qdtype, int prec) {
+    return n_terms >= 1 && n_terms <= MULTI_MAX_TERMS && prec == MOMA_PREC_BF16 && qdtype == MOMA_DT_BF16 && one_pass_dim(d) && B >= 1 &&
+           K >= 1 && plan(B, K, n_terms).nchunk <= COMBINE_MAX_CHUNKS;
+}
+
+hipError_t launch_infonce_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* ws,
+                                hipStream_t st) {
+    const FlashPlan p = plan(B, K, n_terms);
+    const size_t rows = (size_t)p.nchunk * p.Bpad;
+    MultiArgs a{};
+    a.n = n_terms;
+    a.nq = 0;
+    bool with_dq = false;
+    for (int i = 0; i < n_terms; ++i) {
+        int qs = -1;
+        for (int j = 0; j < a.nq; ++j)
+            if (a.qsets[j] == terms[i].q) qs = j;
+        if (qs < 0) { qs = a.nq; a.qsets[a.nq++] = terms[i].q; }
+        a.t[i] = MultiTerm{terms[i].q, terms[i].k, (const bf16_raw*)terms[i].queue, terms[i].loss_rows, terms[i].lse, terms[i].top1,
+                           terms[i].dq, qs};
+        with_dq = with_dq || terms[i].dq != nullptr;
+    }
+    for (int i = 0; i < n_terms; ++i)
+        if (with_dq && terms[i].dq == nullptr) return hipErrorInvalidValue;      // all terms with dq, or none
+    float* m_part = (float*)ws;
+    float* l_part = m_part + (size_t)n_terms * rows;
+    float* x_part = l_part + (size_t)n_terms * rows;
+    uint4* o_part = (uint4*)(((uintptr_t)(x_part + (size_t)n_terms * rows) + 255) & ~(uintptr_t)255);
+    const long o_term_stride = (long)(rows * d * 2 / 16);
+    uint4* qpack = (uint4*)(((uintptr_t)((char*)o_part + (size_t)n_terms * rows * d * 2) + 255) & ~(uintptr_t)255);
+    const long qset_stride = (long)p.Bpad * d * 2 / 16;
+    std::call_once(g_lds_attr_once, set_lds_attrs);
+    const float scale_log2 = inv_T * 1.4426950408889634f;
+    const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;
+    const dim3 grid(p.nbt * p.nchunk * n_terms), block(256);
+#define MOMA_MULTI_LAUNCH(DD)                                                                                                   \
+    do {                                                                                                                        \
+        hipLaunchKernelGGL((infonce_qpack_multi_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4, a.nq), dim3(256), 0, st, a, B, \
+                           scale_log2, qpack, p.Bpad / 32, qset_stride);                                                        \
+        if (with_dq) hipLaunchKernelGGL((infonce_flash_multi_kernel<DD, true>), grid, block, lds, st, a, qpack, qset_stride, B, K, p.nbt, \
+                                        p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, o_term_stride, m_part, l_part, x_part, (long)rows); \
+        else hipLaunchKernelGGL((infonce_flash_multi_kernel<DD, false>), grid, block, lds, st, a, qpack, qset_stride, B, K, p.nbt,    \
+                                p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, o_term_stride, m_part, l_part, x_part, (long)rows);  \
+    } while (0)
+    if (d == 512) MOMA_MULTI_LAUNCH(512);
+    else if (d == 384) MOMA_MULTI_LAUNCH(384);
+    else if (d == 256) MOMA_MULTI_LAUNCH(256);
+    else MOMA_MULTI_LAUNCH(128);
+#undef MOMA_MULTI_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(infonce_combine_multi_kernel, dim3(p.Bpad / 8, with_dq ? d / 32 : 1, n_terms), dim3(256), 0, st, a, B, d, inv_T,
+                       p.nchunk, p.Bpad, o_part, o_term_stride, m_part, l_part, x_part, (long)rows);
     return hipGetLastError();
 }
 

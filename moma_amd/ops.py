@@ -304,6 +304,70 @@ def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = No
     return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec), buf)
 
 
+class _InfoNCEFusedMulti(torch.autograd.Function):
+    """n InfoNCE terms (q_i, k_i, queue_i) in one sweep (moma_infonce_fused_multi): inputs q_0, k_0, queue_0, q_1, ...;
+    outputs loss_rows_0, lse_0, top1_0, loss_rows_1, ..."""
+
+    @staticmethod
+    def forward(ctx, T, prec, *tensors):
+        lib = _lib.load()
+        n = len(tensors) // 3
+        qs = [tensors[3 * i].contiguous() for i in range(n)]
+        ks = [tensors[3 * i + 1].contiguous() for i in range(n)]
+        queues = [tensors[3 * i + 2] for i in range(n)]
+        for q, k, queue in zip(qs, ks, queues):
+            _check_qk(q, k, queue)
+        B, d = qs[0].shape
+        K = queues[0].shape[0]
+        dev = qs[0].device
+        need_grad = any(ctx.needs_input_grad[2 + 3 * i] for i in range(n))
+        ws = torch.empty(lib.moma_infonce_fused_multi_workspace_bytes(n, B, d, K, DT_BF16, prec), device=dev, dtype=torch.uint8)
+        terms = (_lib.InfoNCETerm * n)()
+        outs, dqs = [], []
+        for i in range(n):
+            # (two terms with the same query tensor share its packed image: the library dedupes by pointer)
+            loss_rows = torch.empty(B, device=dev, dtype=torch.float32)
+            lse = torch.empty(B, device=dev, dtype=torch.float32)
+            top1 = torch.empty(B, device=dev, dtype=torch.int32)
+            dq = torch.empty(B, d, device=dev, dtype=torch.float32) if need_grad else None
+            t = terms[i]
+            t.q, t.k, t.queue = qs[i].data_ptr(), ks[i].data_ptr(), queues[i].data_ptr()
+            t.loss_rows, t.lse, t.top1, t.dq = loss_rows.data_ptr(), lse.data_ptr(), top1.data_ptr(), (0 if dq is None else dq.data_ptr())
+            outs += [loss_rows, lse, top1]
+            dqs.append(dq)
+        with _timed("moma_infonce_fused_multi"):
+            check(lib.moma_infonce_fused_multi(C.cast(terms, C.c_void_p), n, B, d, K, float(1.0 / T), _ptr(ws), ws.numel(), DT_BF16,
+                                               prec, _stream()), "moma_infonce_fused_multi")
+        if need_grad:
+            ctx.save_for_backward(*dqs)
+        ctx.n = n
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 3 != 0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dqs = ctx.saved_tensors
+        res = [None, None]
+        for i in range(ctx.n):
+            g_loss = grads[3 * i]
+            res += [dqs[i] * g_loss.unsqueeze(1) if (ctx.needs_input_grad[2 + 3 * i] and g_loss is not None) else None, None, None]
+        return tuple(res)
+
+
+def infonce_fused_multi(terms, T: float, prec="fp32"):
+    """terms = [(q, k, queue), ...] over queues of one shape -> [(loss_rows, lse, top1), ...], computed in ONE sweep
+    (moma_infonce_fused_multi) where the one-pass kernel takes the configuration, else one moma_infonce_fused call per term."""
+    lib = _lib.load()
+    pc = prec_code(prec)
+    q0, _, queue0 = terms[0]
+    same = all(q.shape == q0.shape and queue.shape == queue0.shape and queue.dtype == torch.bfloat16 for q, _, queue in terms)
+    if len(terms) > 1 and same and q0.is_cuda and \
+            lib.moma_infonce_fused_multi_workspace_bytes(len(terms), q0.shape[0], q0.shape[1], queue0.shape[0], DT_BF16, pc) > 0:
+        flat = _InfoNCEFusedMulti.apply(float(T), pc, *[t for term in terms for t in term])
+        return [tuple(flat[3 * i:3 * i + 3]) for i in range(len(terms))]
+    return [infonce_fused(q, k, queue, T, prec) for q, k, queue in terms]
+
+
 # ------------------------------------------------------------------------------------------------
 # K1 batch-token multi-head attention   (MoMA/criterion_moco_att.py:153-167)
 # ------------------------------------------------------------------------------------------------

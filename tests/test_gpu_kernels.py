@@ -615,6 +615,60 @@ def test_dual_queue_memories_golden(ops, golden_dir):
     assert torch.isfinite(q.grad).all() and mem.index == 8
 
 
+@pytest.mark.parametrize("cls_name,B,d,K", [("MoCoST", 256, 512, 65536), ("MoCoSSTT", 256, 512, 16384), ("MoCoSSTT", 100, 128, 4100),
+                                             ("MoCoST", 8, 256, 96)])
+def test_dual_queue_memories_one_sweep(ops, cls_name, B, d, K):
+    """n2 as specified: MoCoST / MoCoSSTT.forward_fused run their 2 / 4 InfoNCE terms in ONE sweep (moma_infonce_fused_multi:
+    one pre-pack over the distinct queries, one launch of the one-pass kernel over both queues, one combine).  Per-term loss
+    and the gradients that reach q / q_t against (a) CrossEntropy over the materialised logits of the reference call sequence
+    (MoMA/mem_moco.py:165-253, exact-fp32 kernels, pinned by G6) and (b) one single-term call per term; queues + pointer
+    bit-equal to the reference sequence's."""
+    import copy
+    from moma_amd import _lib
+    from moma_amd.MoMA import mem_moco
+    torch.manual_seed(B + K)
+    cls = getattr(mem_moco, cls_name)
+    n_terms = 2 if cls_name == "MoCoST" else 4
+    assert _lib.load().moma_infonce_fused_multi_workspace_bytes(n_terms, B, d, K, 1, 1) > 0
+    mem = cls(d, K, 0.15, queue_dtype=torch.bfloat16, precision="bf16").cuda()
+    ref = cls(d, K, 0.15, precision="fp32").cuda()
+    ref.memory_s.copy_(mem.memory_s.float()); ref.memory_t.copy_(mem.memory_t.float())
+    single = copy.deepcopy(mem)
+    nrm = torch.nn.functional.normalize
+    q0, qt0 = nrm(torch.randn(B, d, device="cuda")), nrm(torch.randn(B, d, device="cuda"))
+    k = nrm(q0 + 0.5 * torch.randn(B, d, device="cuda"))
+    kt = nrm(qt0 + 0.5 * torch.randn(B, d, device="cuda"))
+
+    def leaves():
+        return q0.clone().requires_grad_(True), qt0.clone().requires_grad_(True)
+    # (a) the reference call sequence on exact-fp32 kernels
+    q, qt = leaves()
+    out = ref(q, k, kt) if cls_name == "MoCoST" else ref(q, k, q_t=qt, k_t=kt)
+    ref_losses = [torch.nn.functional.cross_entropy(lg, out[-1]) for lg in out[:-1]]
+    sum(ref_losses).backward()
+    ref_gq, ref_gqt = q.grad.clone(), (qt.grad.clone() if qt.grad is not None else None)
+    # the one-sweep form
+    q, qt = leaves()
+    losses, accs = mem.forward_fused(q, k, kt) if cls_name == "MoCoST" else mem.forward_fused(q, k, q_t=qt, k_t=kt)
+    assert len(losses) == n_terms and len(accs) == n_terms
+    sum(losses).backward()
+    for a, b in zip(losses, ref_losses):
+        assert abs(a.item() - b.item()) < 1e-3 * max(1.0, abs(b.item())), (a.item(), b.item())
+    assert (q.grad - ref_gq).abs().max().item() < 3e-2 * ref_gq.abs().max().item()
+    if ref_gqt is not None:
+        assert (qt.grad - ref_gqt).abs().max().item() < 3e-2 * ref_gqt.abs().max().item()
+    assert mem.index == ref.index
+    assert torch.equal(mem.memory_s, ref.memory_s.to(torch.bfloat16)) and torch.equal(mem.memory_t, ref.memory_t.to(torch.bfloat16))
+    # (b) one single-term call per term on the same (pre-enqueue) queues: same kernels, another key-chunk split
+    q2, qt2 = leaves()
+    pairs = [(q2, k, single.memory_s), (q2, kt, single.memory_t)] + ([(qt2, k, single.memory_s), (qt2, kt, single.memory_t)] if n_terms == 4 else [])
+    s_losses = [ops.infonce_fused(a, b, c, 0.15, "bf16")[0].mean() for a, b, c in pairs]
+    sum(s_losses).backward()
+    for a, b in zip(losses, s_losses):
+        assert abs(a.item() - b.item()) < 2e-5 * max(1.0, abs(b.item()))
+    assert (q.grad - q2.grad).abs().max().item() < 1e-3 * q2.grad.abs().max().item()
+
+
 def test_mocoatt_cross_attention_variants_golden(ops, golden_dir):
     """MoCoAtt.forward (reference MoMA/mem_moco.py:103-161): every attn variant against vectors from the reference --
     logits, gradient w.r.t. the student query through the attention modules, enqueued queue, pointer."""
