@@ -36,37 +36,8 @@
 #include <mutex>
 #include <type_traits>
 
-#ifdef MOMA_K2_STAMPS
-// Diagnostic build only (never the product): per-wave cycle stamps of the one-pass kernel.  Nothing of a stamp stays in a
-// register (the kernel has none to spare: live stamp values push it into spills): every stamp is added to / subtracted
-// from a word of LDS behind the tile ring, copied out to this buffer at the end of the kernel.
-//   word 0..2: per-tile phase sums (scores, P.K || softmax, wait + barrier); 3: entry -> first barrier; 4: first tile;
-//   5: tile loop; 6: epilogue issue.
-__device__ unsigned moma_k2_stamps[1024 * 16];
-extern "C" int moma_debug_read_stamps(unsigned* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma_k2_stamps), sizeof(unsigned) * 1024 * 16);
-}
-#define K2_STAMP_BYTES 512
-// stamp now: word `neg` -= t, word `pos` += t  (either may be -1)
-#define K2_STAMP(neg, pos)                                                                                   \
-    do {                                                                                                     \
-        unsigned long long _t64;                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t64)::"memory");                         \
-        const unsigned _t = (unsigned)_t64;                                                                  \
-        const unsigned _a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem) + (unsigned)(NBUF * TILE_BYTES + 16 + wave * 64); \
-        if ((neg) >= 0) asm volatile("ds_sub_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((neg) < 0 ? 0 : (neg) * 4) : "memory"); \
-        if ((pos) >= 0) asm volatile("ds_add_u32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" ::"v"(_a), "v"(_t), "n"((pos) < 0 ? 0 : (pos) * 4) : "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-    } while (0)
-#else
-#define K2_STAMP_BYTES 0
-#define K2_STAMP(neg, pos) do { } while (0)
-#endif
-
-#ifndef MOMA_K2_WPV_SD
+// Tuning constants of the kernels below (each fixed by measurement on MI355X; DESIGN.md section 4 records the sweeps):
 #define MOMA_K2_WPV_SD 3        // wide P.K pass: key tiles (and their P) requested ahead; ring of SD + 1 slots of 16 KiB
-#endif
 
 namespace moma {
 namespace {
@@ -198,11 +169,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, h = lane >> 5;
-#ifdef MOMA_K2_STAMPS
-    if (lane < 16) reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 16 + lane] = 0u;
-    K2_STAMP(3, -1);
-    K2_STAMP(7, -1);
-#endif
 
     // block -> (query tile, key chunk): the nbt tiles of one chunk are 8 block ids apart (same XCD)
     int bt, chunk;
@@ -255,18 +221,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             const char* qb = reinterpret_cast<const char*>(qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-#ifndef MOMA_K2_ABL_NO_QLOAD
                 asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[ks]) : "v"(qb + (ks >> 2) * 4096), "n"((ks & 3) * 1024) : "memory");
-#else
-                asm volatile("" : "=v"(qf[ks]) : "v"(qb));
-#endif
             }
         }
     };
-#ifndef MOMA_K2_T0_FIRST
     load_q();
-#endif
-    K2_STAMP(8, 7);
 
     // LDS-DMA ring.  Every wave issues PPW pieces per tile, in tile order, so "all but the newest j tiles of
     // this wave have landed" is s_waitcnt vmcnt(j*PPW); the workgroup barrier then makes the other waves'
@@ -283,9 +242,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 
     // the whole ring is requested up front (Q first: the first score needs all of it, the tiles one after the other)
     const int npro = min(t1 - t0, NBUF);
-#ifndef MOMA_K2_PRO
 #define MOMA_K2_PRO 4
-#endif
     // Tiles requested BEFORE the first wait.  An LDS-DMA piece costs ~150 cycles of issue when nothing else runs (the CU's
     // address path moves 64 B/clk: the 4 x 32 KiB ring alone is 2 k cycles of it, measured 4.7 k) and ~nothing in the shadow of
     // MFMAs, so the pipelined kernel requests only two tiles up front and fills the rest of the ring from the first tile's
@@ -297,13 +254,9 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
             if (j >= jb && j < je && j < npro) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
-#ifdef MOMA_K2_T0_FIRST
-            if constexpr (decltype(first_pass)::value) { if (j == 0 && jb == 0) load_q(); }
-#endif
         }
     };
     issue_ring(std::true_type{}, 0, PRO);
-    K2_STAMP(9, 8);
 
     f32x16 O[WITH_DQ ? NCT : 1];
     float l_run = 0.f, mx = NEG_BIG;
@@ -329,9 +282,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // reads behind the MFMAs and exposes the LDS latency once per group).  One LDS-DMA piece of the refill tile is
     // issued after every 4th MFMA, so its issue cost hides behind the matrix pipe.
     auto wait_lgkm = [&](int n) __attribute__((always_inline)) {          // n is a constant after unrolling
-#ifdef MOMA_K2_ABL_NO_LGKM_SCORE
-        return;                                                          // (timing experiment only: results are garbage)
-#endif
         switch (n) {
             case 15: asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); break;
             case 14: asm volatile("s_waitcnt lgkmcnt(14)" ::: "memory"); break;
@@ -356,12 +306,8 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // takes 4 reads (lo: k-step 0, hi: k-step 1) into buffer c % (PF+1); they are counted by hand (LDS returns in order).
     // The state lives at function scope so that the pipelined loop can issue the FIRST PF column tiles of P.K(t) in the tail
     // of the score product of tile t+1 (no pipeline-fill bubble between the two MFMA phases).
-#ifndef MOMA_K2_ROT
 #define MOMA_K2_ROT 1          // pipelined loop: next tile's first A fragments requested behind the end-of-iteration barrier
-#endif
-#ifndef MOMA_K2_PF
 #define MOMA_K2_PF 2
-#endif
     constexpr int PF = MOMA_K2_PF;                     // column tiles of transposed reads in flight
     s16x4 kb[PF + 1][4];
     unsigned ba[4][2];
@@ -377,31 +323,21 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         s16x4* k4 = kb[c % (PF + 1)];
         const int imm = (c >> 2) * 8192;
         (void)imm;
-#ifndef MOMA_K2_ABL_NO_PV_LDS
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[0]) : "v"(ba[c & 3][0]), "i"(imm) : "memory");
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[1]) : "v"(ba[c & 3][1]), "i"(imm + 2048) : "memory");
-#else
-        asm volatile("" : "=v"(k4[0]), "=v"(k4[1]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
-#endif
     };
     auto issue_hi = [&](int c) __attribute__((always_inline)) {
         s16x4* k4 = kb[c % (PF + 1)];
         const int imm = (c >> 2) * 8192;
         (void)imm;
-#ifndef MOMA_K2_ABL_NO_PV_LDS
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[2]) : "v"(ba[c & 3][0]), "i"(imm + 4096) : "memory");
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(ba[c & 3][1]), "i"(imm + 6144) : "memory");
-#else
-        asm volatile("" : "=v"(k4[2]), "=v"(k4[3]) : "v"(ba[c & 3][0]), "v"(ba[c & 3][1]));
-#endif
     };
 
     // pvpre_tag (true_type): the last 2*PF gaps of the product also issue the first PF column tiles of the transposed reads of
     // `pvbuf` (the tile P.K runs on next), two reads per gap; the product's own waits then count those younger reads too, and
     // the s_nops behind the last MFMA are dropped (the caller keeps every VALU reader of x behind >= 4 further MFMAs).
-#ifndef MOMA_K2_RD
 #define MOMA_K2_RD 4      // (with the rotated loop the first fragments are early anyway; 6 and 8 spill at D = 512)
-#endif
     constexpr int RD = MOMA_K2_RD < KS ? MOMA_K2_RD : KS;                             // LDS read distance in k-steps (RD x 32 cycles)
     static_assert(RD <= 12 && RD <= KS, "lgkmcnt is a 4-bit counter");
     // A fragments of the score product (keys, row-wise): a ring of RD k-steps, requested by inline asm and counted by hand
@@ -411,11 +347,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     f32x4 kf[RD];
     unsigned aa[8];
     auto rd = [&](int ks) __attribute__((always_inline)) {
-#ifndef MOMA_K2_ABL_NO_SCORE_LDS
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");
-#else
-        asm volatile("" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]));
-#endif
     };
     auto score_begin = [&](const char* buf) __attribute__((always_inline)) {
         const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
@@ -448,12 +380,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         f32x16 c0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c0[r] = init;
-#ifdef MOMA_K2_DMA_FRONT
-        if constexpr (REFILL != 0) {
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) dma_piece<D, REFILL == 2>(i, dl, queue, rkey0, K, rbuf, wave, lane);
-        }
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -465,17 +391,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // inline-asm MFMA pins the score accumulator to VGPRs (through the builtin hipcc puts it in a[0:15] and
             // moves O's first column tile out and back every tile).  Hazards by hand: s_nop before the first MFMA
             // (VALU-written C), s_nops after the last one (VALU readers of D).
-#ifndef MOMA_K2_ABL_NO_SCORE_MFMA
             if (ks == 0)
                 asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "v"(c0));
             else if (ks == KS - 1 && !PVPRE)
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
             else
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
-#else
-            if (ks == 0) asm volatile("" : "=&v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "v"(c0));
-            else asm volatile("" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));
-#endif
             if (ks + RD < KS) rd(ks + RD);
             if constexpr (PVPRE) {
                 static_assert(NPRE <= KS && PF <= NCT, "tail gaps and column tiles exist");
@@ -487,9 +408,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 }
             }
             if constexpr (REFILL != 0) {
-#if !defined(MOMA_K2_ABL_NO_LOOP_DMA) && !defined(MOMA_K2_DMA_FRONT)
                 if ((ks & 3) == 1) dma_piece<D, REFILL == 2>(ks >> 2, dl, queue, rkey0, K, rbuf, wave, lane);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -574,29 +493,19 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             for (int c = 0; c < NCT; ++c) {
                 // in flight when tile c's first MFMA issues: all of c+1 .. c+PF-1, nothing of c+PF yet
                 const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
-#ifndef MOMA_K2_ABL_NO_LGKM_PV                                     // (defined: timing experiment only, results are garbage)
                 if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
                 else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 s16x4* k4 = kb[c % (PF + 1)];
                 const s16x8 k0 = __builtin_shufflevector(k4[0], k4[1], 0, 1, 2, 3, 4, 5, 6, 7);
                 const s16x8 k1 = __builtin_shufflevector(k4[2], k4[3], 0, 1, 2, 3, 4, 5, 6, 7);
-#ifndef MOMA_K2_ABL_NO_PV_MFMA
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], __builtin_bit_cast(bf16x8, k0), O[c], 0, 0, 0);
-#else
-                asm volatile("" ::"v"(k0), "v"(pa[0]));
-#endif
                 if (c + PF < NCT) issue_lo(c + PF);               // LDS requests in the first MFMA's shadow
                 between_a(c);                                      // (the gap behind the first MFMA carries no wait: room for 12 cycles)
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef MOMA_K2_ABL_NO_PV_MFMA
                 O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), O[c], 0, 0, 0);
-#else
-                asm volatile("" ::"v"(k1), "v"(pa[1]));
-#endif
                 if (c + PF < NCT) issue_hi(c + PF);
                 between(c);                                        // one softmax step in the second MFMA's shadow
                 __builtin_amdgcn_sched_barrier(0);
@@ -610,7 +519,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     };
     auto store_tile = [&](uint4* dst, int c) __attribute__((always_inline)) {
         if constexpr (WITH_DQ) {
-#ifndef MOMA_K2_ABL_NO_EPI_STORE
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint4 v;
@@ -620,9 +528,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 v.w = (unsigned)f32_to_bf16(O[c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g + 7]) << 16);
                 dst[(c * 2 + g) * 64] = v;     // (non-temporal stores: same kernel time, +3 us on the combine that reads them back)
             }
-#else
-            asm volatile("" ::"v"(O[c]));
-#endif
         }
     };
 
@@ -654,17 +559,13 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     mx = NEG_BIG;
     ovf = 0;
     // Q and tile t0 have landed (the rest of the ring stays in flight); from here on the Q registers may be read
-    if constexpr (!repass) K2_STAMP(10, 9);
     wait_tiles_in_flight(min(npro, PRO) - 1);
-    if constexpr (!repass) K2_STAMP(-1, 10);
     if constexpr (MODE != 2) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
     __builtin_amdgcn_s_barrier();
     if constexpr (PRO < NBUF && !PIPELINED) issue_ring(std::false_type{}, PRO, NBUF);
-    if constexpr (!repass) K2_STAMP(-1, 3);
-    if constexpr (!repass) K2_STAMP(4, -1);
 
     if constexpr (PIPELINED) {
         // ---- software-pipelined main loop (one wave per SIMD: nothing else hides the softmax's VALU time):
@@ -679,30 +580,18 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // tile t0+1 must have landed before the loop's first score (t0+2 may stay in flight)
         wait_tiles_in_flight(max(min(t0 + 2, t1 - 1) - (t0 + 1), 0));
         __builtin_amdgcn_s_barrier();
-        if constexpr (!repass) K2_STAMP(-1, 4);
-        if constexpr (!repass) K2_STAMP(5, -1);
         // every iteration of the loop has a next tile; the chunk's LAST tile is peeled off below
-#ifdef MOMA_K2_ABL_NO_LOOP
-        const int tlast = t0;
-#else
         const int tlast = t1 - 1;
-#endif
         if (MOMA_K2_ROT && t0 < tlast) score_begin(slot(t0 + 1));            // first A fragments of the loop's first score product
 #pragma unroll 1
         for (int t = t0; t < tlast; ++t) {
             f32x16 xb;
-#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
-            K2_STAMP(0, -1);
-#endif
             {
                 // the slot of tile t-1 (free since the barrier that ended iteration t-1; never used yet at t = t0) takes tile t+NBUF-1;
                 // the product's tail already requests the first column tiles of P.K(t): the two MFMA phases run back to back
                 const bool refill = t + NBUF - 1 < t1;
                 score_dispatch_pv(slot(t + 1), xb, -m_ref, refill, t + NBUF - 1, slot(t));
             }
-#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
-            K2_STAMP(1, 0);
-#endif
             float tmax = NEG_BIG, psum = 0.f;
             // One softmax step (register j of the score tile: running max, 2^x, running sum) per P.K column tile.  xb holds
             // score - m_ref.  The exponential and the sum are inline asm: as plain expressions hipcc sinks them to their use
@@ -710,23 +599,17 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             // sum lags one step (no instruction reads a transcendental result right behind its v_exp_f32).  The steps start
             // SM_SHIFT column tiles into P.K: the score MFMAs were issued without trailing wait states, and no VALU may read
             // their accumulator before >= 4 further MFMAs have gone by.
-#ifndef MOMA_K2_SM_SHIFT
 #define MOMA_K2_SM_SHIFT 2
-#endif
             constexpr int SM_SHIFT = MOMA_K2_SM_SHIFT;
             // The step is split over the two gaps of a column tile: maximum + exponential (12 issue cycles) behind the first MFMA,
             // whose gap carries only the two reads; the sum behind the second, whose gap also carries the wait (a whole step
             // there made that gap 36 cycles against the MFMA's 32, while the first one idled).
             auto sm_step_a = [&](int j) __attribute__((always_inline)) {
-#ifndef MOMA_K2_ABL_NO_SOFTMAX
                 asm volatile("v_max_f32 %0, %0, %1" : "+v"(tmax) : "v"(xb[j]));       // (pinned here: left to hipcc the maxima sink
                 asm volatile("v_exp_f32 %0, %0" : "+v"(xb[j]));                       //  behind the barrier and every x is copied first)
-#endif
             };
             auto sm_step_b = [&](int j) __attribute__((always_inline)) {
-#ifndef MOMA_K2_ABL_NO_SOFTMAX
                 if (j >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(psum) : "v"(xb[j - 1]));
-#endif
             };
             auto sm_step = [&](int j) __attribute__((always_inline)) { sm_step_a(j); sm_step_b(j); };
             pv(std::true_type{}, slot(t), pa,
@@ -742,20 +625,11 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
                 if (NCT <= SM_SHIFT && j == 0) mask_tail(xb, t + 1);
                 sm_step(j);
             }
-#ifndef MOMA_K2_ABL_NO_SOFTMAX
             psum += xb[15];
-#endif
-#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
-            K2_STAMP(2, 1);
-#endif
             // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
-#ifndef MOMA_K2_ABL_NO_DMA_WAIT
             if (t + NBUF - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");     // (one two-way branch, not the general switch)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifndef MOMA_K2_ABL_NO_LOOP_BARRIER
             __builtin_amdgcn_s_barrier();
-#endif
             // the next iteration's first A fragments are requested right here, and the bookkeeping of THIS tile runs under
             // their LDS latency: per-lane-half statistics (tmax is relative to m_ref; the two halves of a row are merged once
             // after the loop -- a cross-half shuffle here would be an LDS round trip on the critical path of every tile) and
@@ -765,12 +639,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             mx = fmaxf(mx, tmax + m_ref);                       // back to absolute log2 units
             l_run += psum;
             pack(xb, pa);
-#if defined(MOMA_K2_STAMPS) && MOMA_K2_STAMPS >= 2
-            K2_STAMP(-1, 2);
-#endif
         }
-        if constexpr (!repass) K2_STAMP(-1, 5);
-        if constexpr (!repass) K2_STAMP(6, -1);
         // ---- last tile: O += P.K, with the partial of column tile c-1 converted and stored in the shadow of tile c's MFMAs
         // (nothing else is left to hide there; done after the loop the 256 accumulator reads, 128 conversions and 32 stores
         // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
@@ -860,12 +729,6 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#ifdef MOMA_K2_STAMPS
-    if constexpr (PIPELINED) {
-        K2_STAMP(-1, 6);
-        if (lane < 16) moma_k2_stamps[((blockIdx.x * 4 + wave) & 1023) * 16 + lane] = reinterpret_cast<unsigned*>(smem + NBUF * TILE_BYTES + 16)[wave * 16 + lane];
-    }
-#endif
 }
 
 template <int D, bool WITH_DQ>
@@ -1744,7 +1607,7 @@ namespace {
 // dynamic-LDS opt-in of every instantiation, once per process (hipFuncSetAttribute is not a stream operation)
 std::once_flag g_lds_attr_once;
 void set_lds_attrs() {
-    const int mx = NBUF * KT * 512 * 2 + 16 + K2_STAMP_BYTES;
+    const int mx = NBUF * KT * 512 * 2 + 16;
 #define MOMA_SET_LDS(DD)                                                                                                        \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);     \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);    \
@@ -1819,7 +1682,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
                 const int D = slab_width(col0);
                 const SlabArgs sa{xs, nullptr, (unsigned)(d * 2), col0 == 0 ? 1 : 0};
-                const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
+                const size_t slds = (size_t)NBUF * KT * D * 2 + 16;
 #define MOMA_SLAB_SCORES(DD)                                                                                             \
                 do {                                                                                                         \
                     hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, col0, scale_log2, qpack, p.Bpad / 32); \
@@ -1856,7 +1719,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 for (int col0 = 0; col0 < d; col0 += slab_width(col0), ++sl) {
                     const int D = slab_width(col0);
                     const SlabArgs sa{xs, m_part, (unsigned)(d * 2), 0};
-                    const size_t slds = (size_t)NBUF * KT * D * 2 + 16 + K2_STAMP_BYTES;
+                    const size_t slds = (size_t)NBUF * KT * D * 2 + 16;
                     uint4* op = (uint4*)((char*)o_part + (size_t)sl * slab_bytes);
 #define MOMA_SLAB_PV(DD) hipLaunchKernelGGL((infonce_slab_kernel<DD, 2>), grid, block, slds, st, qpack, qu + col0, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, op, sa)
                     if (D == 512) MOMA_SLAB_PV(512); else if (D == 384) MOMA_SLAB_PV(384); else if (D == 256) MOMA_SLAB_PV(256); else MOMA_SLAB_PV(128);
@@ -1867,14 +1730,13 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         if (ev_end && !ev_on_dispatch) (void)hipEventRecord(ev_end, st);      // (slab passes: recorded behind the last pass)
         {
             int tpb = 4;                                           // (measured at d = 1280: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call)
-            if (const char* e = getenv("MOMA_K2_COMBINE_TPB")) tpb = atoi(e) > 0 ? atoi(e) : tpb;       // (diagnostic override)
             const int nty = dq ? (d / 32 + tpb - 1) / tpb : 1;
             hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, nty), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
                                o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, tpb, wide_ref);
         }
         return hipGetLastError();
     }
-    const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;      // ring + the 4 overflow words
+    const size_t lds = (size_t)NBUF * KT * d * 2 + 16;      // ring + the 4 overflow words
 #define MOMA_FLASH_ARGS qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part
     if (q_packed != nullptr) qpack = (uint4*)q_packed;
 #define MOMA_FLASH_LAUNCH(DD)                                                                             \
@@ -1937,7 +1799,7 @@ hipError_t launch_infonce_multi(const moma_infonce_term_t* terms, int n_terms, i
     const long qset_stride = (long)p.Bpad * d * 2 / 16;
     std::call_once(g_lds_attr_once, set_lds_attrs);
     const float scale_log2 = inv_T * 1.4426950408889634f;
-    const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + K2_STAMP_BYTES;
+    const size_t lds = (size_t)NBUF * KT * d * 2 + 16;
     const dim3 grid(p.nbt * p.nchunk * n_terms), block(256);
 #define MOMA_MULTI_LAUNCH(DD)                                                                                                   \
     do {                                                                                                                        \
