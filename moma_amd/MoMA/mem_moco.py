@@ -140,8 +140,9 @@ class MoCoAtt(BaseMoCo):
       'dual2'   atts_p over [q ; k] -> q, atts_n over [k ; q] -> k, positive logit only
       'all'     one module over [q ; k ; queue]      'dual'  atts_p over [q ; queue], atts_n over [k ; queue]
       default   atts_q(q), atts_k(k), atts_queue(queue)
-    The variants that attend over the queue materialise [H, N, N] scores with N = K (+B / +2B), exactly like the
-    reference, so they are only usable with small K."""
+    The variants that attend over the queue ('all', 'dual', default) run the attention flash-style on the K1 fast path
+    (row log-sum-exp kept, P recomputed per tile in the backward): no [H, N, N] array exists, N = K + B / 2B tokens are
+    fine (tested at N = 8224); only the exact-fp32 policy materialises the scores like the reference."""
 
     def __init__(self, n_dim, K=65536, T=0.07, mem_name="memory", queue_dtype=torch.float32, precision="fp32"):
         super().__init__(K, T, precision)

@@ -46,12 +46,17 @@ class ContrastTrainer(BaseTrainer):
         tab = tabs.get(key)
         if tab is None or not tab.matches(ps, es):       # (matches() also catches an id reused by a new model)
             tab = ops.EmaTable(ps, es)
+            # the kernel writes the EMA weights through raw pointers (no autograd version bump): attention modules among them
+            # keep bf16 weight packs keyed on those versions and have to be told
+            tab.packed = [mod for mod in model_ema.modules() if hasattr(mod, "invalidate_pack")]
             tabs[key] = tab
             while len(tabs) > ContrastTrainer._EMA_TABLES_MAX:
                 tabs.popitem(last=False)
         else:
             tabs.move_to_end(key)
         ops.ema_update_(tab, m)
+        for mod in getattr(tab, "packed", ()):
+            mod.invalidate_pack()
 
     # -- collectives ------------------------------------------------------------------------------
     def broadcast_memory(self, contrast):
