@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--head", default="mlp", choices=["None", "linear", "mlp"])
     p.add_argument("--feat_dim", type=int, default=512)
     p.add_argument("--model", default="effiB0")
+    p.add_argument("--model_t", default=None, help="teacher architecture (default: the student's; a different one keeps the "
+                                                   "teacher frozen -- BASELINE configs[4]: --model ResNet50 --model_t vit_base_patch16_224)")
     p.add_argument("--n_cls", type=int, default=4)
     p.add_argument("--moma_prec", default="bf16", choices=["fp32", "bf16"])
     p.add_argument("--queue_dtype", default="bf16", choices=["fp32", "bf16"])
@@ -195,13 +197,14 @@ def make_opt(a, rank, world):
         distill="moma", head=a.head, feat_dim=a.feat_dim, attn="self", mem="MoCo", nce_k=a.nce_k, nce_t=0.15,
         alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=int(os.environ.get("LOCAL_RANK", 0)),
         multiprocessing_distributed=world > 1, print_freq=10 ** 9, batch_size=a.batch_size, rank=rank,
-        world_size=world, model_s=a.model, model_t=a.model, std_pre=None, tec_pre=None, path_t=None,
+        world_size=world, model_s=a.model, model_t=a.model_t or a.model, std_pre=None, tec_pre=None, path_t=None,
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=0.05, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
         shuffle_bn="per_rank", num_heads=4,
         # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
-        overlap_teacher=a.overlap_teacher and os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1")
+        overlap_teacher=a.overlap_teacher and (os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1" or
+                                               os.environ.get("MOMA_BENCH_FORCE_OVERLAP") == "1"))
 
 
 def log(*a):
@@ -303,6 +306,8 @@ def main():
     torch.manual_seed(12345)                         # identical initial weights on every rank
     model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
     trainer = ContrastTrainer(opt)
+    if opt.amp == "fp16":
+        opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if world > 1:
         ddp_s = nn.parallel.DistributedDataParallel(model_s, device_ids=[local], gradient_as_bucket_view=True)
         opt.gpu = local
@@ -378,8 +383,18 @@ def main():
         log("per-step ms (gpu | host issue): " + " ".join(f"{g:.1f}|{h:.1f}" for g, h in zip(step_gpu, step_host)))
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    spread = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # replicas must still be bit-identical: student (DDP all-reduce), trainable criterion modules (the hook-launched flat
+        # all-reduce), EMA teacher (updated locally from identical student weights)
+        def csum(mod):
+            return torch.stack([p.detach().double().sum() for p in mod.parameters()]).sum()
+        mine = torch.stack([csum(model_s), csum(criterion_list[2]), csum(model_t)])
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = [float(v) for v in (hi - lo).tolist()]
     dt = float(t.item())
 
     if rank == 0:
@@ -438,7 +453,9 @@ def main():
             "ms_first_step": round(step_gpu[0], 3) if step_gpu else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {a.model} student+teacher (random init), synthetic "
+            "config": {"workload": (f"BASELINE configs[1]: {a.model} student+teacher" if (a.model_t or a.model) == a.model else
+                                    f"BASELINE configs[4], single-GPU form: {a.model} student <- {a.model_t} teacher (frozen: architectures differ)") +
+                                   f" (random init), synthetic "
                                    f"{a.image_size}x{a.image_size} RGB, per-GPU batch {a.batch_size}, queue K={a.nce_k} "
                                    f"x d={d} ({a.queue_dtype}), head={a.head}, attn=self (4 heads), -c 1 -d 1 -b 1, "
                                    f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp} (BN+SiLU / depthwise / SE on the library's helper "
@@ -449,6 +466,8 @@ def main():
         }
         if world > 1:      # what the N>1 line was measured with (the driver checks it against its own launch)
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "replica_checksum_spread": {"student": spread[0], "criterion": spread[1], "ema_teacher": spread[2]},
+                           "overlap_teacher": bool(opt.overlap_teacher), "graph_teacher": bool(getattr(opt, "graph_teacher", True)),
                            "collective": "DDP bucketed gradient all-reduce (student) + one flat async all-reduce of the "
                                          "trainable criterion modules per step; per-rank queue, no data-path gather"}
         log(f"timed region: {dt:.2f} s; {out['value']} images/sec")

@@ -134,3 +134,27 @@ def test_cli_config5_cross_arch_vit_base_to_resnet50_fp16(tmp_path):
     params = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith("parameters.json")]
     p = json.load(open(params[0]))
     assert p["s_dim"] == 2048 and p["t_dim"] == 768 and p["feat_dim"] == 512
+
+
+def test_bench_two_ranks_on_one_gpu_replicas_stay_in_sync(tmp_path):
+    """The combination the driver's multi-GPU run hits first, rehearsed on ONE GPU: `python -m torch.distributed.run` with two
+    ranks -> bench.py --gpus 2 (gloo carries the collectives: RCCL refuses two ranks on one device), DDP + the hook-launched
+    flat all-reduce of the criterion gradients + HIP-graphed teacher + teacher side on a second stream, all ON.  After warm-up
+    and timed steps the replicas must be BIT-identical (student, criterion modules, EMA teacher) and the JSON line must carry
+    the N > 1 fields."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MOMA_BENCH_SAME_DEVICE="1", MOMA_BENCH_BACKEND="gloo", MOMA_BENCH_FORCE_OVERLAP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
+           "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
+    d = out["dist"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["overlap_teacher"] and d["graph_teacher"]
+    assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}, d
