@@ -132,6 +132,7 @@ int moma_infonce_logits_bwd_kq(const float* dlogits, const float* q, float* dk, 
 size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec) {
     if (B <= 0 || d <= 0 || K <= 0) return 0;
     if (infonce_flash_supported(B, d, K, qdtype, prec)) return infonce_flash_workspace_bytes(B, d, K);
+    if (infonce_f32_flash_supported(B, d, K, qdtype, prec)) return infonce_f32_flash_workspace_bytes(B, d, K);
     return align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256);
 }
 
@@ -166,6 +167,9 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     if (infonce_flash_supported(B, d, K, qdtype, prec))
         return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,
                                            (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed));
+    if (infonce_f32_flash_supported(B, d, K, qdtype, prec))      // exact fp32, fp32 queue: one pass, no [B,K+1] logits
+        return hip_rc(launch_infonce_f32_flash(q, k, (const float*)queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, st,
+                                               (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
     // staged path (any shape, exact fp32 available): logits -> row reduction -> gradient product
     float* logits = (float*)workspace;
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, st);

@@ -97,6 +97,13 @@ size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K);
 hipError_t launch_infonce_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* ws,
                                 hipStream_t st);
 
+// ---- infonce_f32.hip (one pass over an fp32 queue in exact fp32 arithmetic) ------------------------
+bool infonce_f32_flash_supported(int B, int d, int K, int qdtype, int prec);
+size_t infonce_f32_flash_workspace_bytes(int B, int d, int K);
+hipError_t launch_infonce_f32_flash(const float* q, const float* k, const float* queue, int B, int d, int K, float inv_T,
+                                    float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, hipStream_t st,
+                                    hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+
 // ---- k1_fast.hip (batch-token attention, bf16 fast path) -------------------------------------------
 bool mha_fast_supported(int N, int d, int H, int prec);
 hipError_t launch_mha_pack(const float* w_qkv, const float* w_proj, void* pack, int d, int with_t, hipStream_t st);

@@ -268,6 +268,63 @@ def test_infonce_flash_overflow_repass(ops, scale, d, grad):
         np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
 
 
+@pytest.mark.parametrize("B,d,K", [(256, 512, 65536), (100, 256, 5000), (33, 128, 777), (8, 512, 40), (1, 128, 100), (64, 512, 4097)])
+def test_infonce_f32_policy_is_one_pass(ops, B, d, K):
+    """The reference's OWN arithmetic (fp32; MoMA/mem_moco.py:29-49,77-100 + CrossEntropy) as one pass over the fp32 queue on the
+    f32-input MFMA (infonce_f32.hip): no [B,K+1] logits (the workspace is the chunk partials), loss / lse / top-1 / dq against the
+    fp64 oracle at the fp32 tolerance of the staged path it replaces, forward-only == with-gradient, bitwise repeatable."""
+    from moma_amd import _lib
+    rng = np.random.default_rng(B + d + K)
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    T = 0.15
+    ws = _lib.load().moma_infonce_fused_workspace_bytes(B, d, K, 0, 0)
+    assert ws > 0 and (K < 65536 or ws < B * (K + 1) * 4 // 2)        # chunk partials, not a [B,K+1] logits matrix
+    ref = O.infonce_loss(O.compute_logit(q, k, queue, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, queue, T) * B
+    tqueue = _t(queue)
+    outs = []
+    for _ in range(2):
+        tq = _t(q).requires_grad_(True)
+        loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), tqueue, T, "fp32")
+        loss_rows.sum().backward()
+        outs.append((loss_rows.detach().clone(), lse.clone(), top1.clone(), tq.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    loss_rows, lse, top1, dq = outs[0]
+    assert abs(loss_rows.mean().item() - ref["loss"]) < 2e-5 * max(1.0, abs(ref["loss"]))
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=2e-5, atol=1e-4)
+    assert np.array_equal(top1.cpu().numpy().astype(bool), ref["top1"])
+    np.testing.assert_allclose(dq.cpu().numpy(), ref_dq, rtol=0, atol=2e-5 * np.abs(ref_dq).max())
+    fwd = ops.infonce_fused(_t(q), _t(k), tqueue, T, "fp32")
+    assert torch.equal(fwd[0], loss_rows) and torch.equal(fwd[1], lse) and torch.equal(fwd[2], top1)
+
+
+@pytest.mark.parametrize("scale", [30.0, 10.0])
+@pytest.mark.parametrize("d", [128, 512])
+def test_infonce_f32_flash_overflow_repass(ops, scale, d):
+    """The fixed softmax reference of the fp32 one-pass kernel (first tile's max + 32) with a key far down the chunk that beats it
+    by ~290 log2 units (scale 30: beyond the 128 of headroom -> the workgroup repeats its chunk with the true row maxima) or ~96
+    (scale 10: carried by the single pass).  Guide rule 26: the rare branch gets its own forced test, full fp64 reference."""
+    rng = np.random.default_rng(7)
+    B, K, T = 40, 3000, 0.15
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    queue[1500] = scale * q[5] / np.linalg.norm(q[5])
+    queue[2999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
+    ref = O.infonce_loss(O.compute_logit(q, k, queue, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, queue, T) * B
+    tq = _t(q).requires_grad_(True)
+    loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), _t(queue), T, "fp32")
+    loss_rows.sum().backward()
+    assert np.all(np.isfinite(lse.cpu().numpy()))
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=2e-5, atol=2e-4)
+    assert abs(loss_rows.mean().item() - ref["loss"]) < 2e-5 * abs(ref["loss"])
+    np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=3e-5 * np.abs(ref_dq).max())
+
+
 def test_infonce_flash_forward_only_matches_grad_path(ops):
     """The forward-only kernel (no dq requested) and the pipelined kernel give the same loss / lse / top-1."""
     rng = np.random.default_rng(11)
