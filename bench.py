@@ -418,6 +418,7 @@ def main():
             if tr is not None:
                 roof["traffic"], roof["traffic_source"] = tr[0], tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/bench_k2.py; not measured in this run)"
         k1f, k1b, k4 = rec.mean_ms("moma_mha_fwd"), rec.mean_ms("moma_mha_bwd"), rec.mean_ms("moma_ema_multi")
+        k1g = rec.mean_ms("moma_mha_fwd_group2")
         n_par = sum(p.numel() for p in model_s.parameters())
         d_att = d
         other = {"pmc": pmc_fracs()}
@@ -429,9 +430,11 @@ def main():
         if k1f:
             fl = 8.0 * a.batch_size * d_att * d_att + 4.0 * a.batch_size * a.batch_size * d_att
             other["k1_attention"] = {"fwd_ms_per_module_call": round(k1f, 4), "bwd_ms_per_call": round(k1b, 4) if k1b else None,
+                                     "fwd_ms_two_modules_grouped": round(k1g, 4) if k1g else None,
                                      "fwd_flops": fl, "fwd_mfma_frac_wallclock": round(fl / (k1f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5),
-                                     "note": "launch / latency bound at N = batch (0.67 GFLOP per module call): the in-kernel "
-                                             "matrix-pipe share is in pmc.mha_core_*"}
+                                     "note": "launch / latency bound at N = batch (0.67 GFLOP per module call); HIP events around the C-ABI "
+                                             "call (3 launches each; atts_k + atts_queue run as ONE group of 3 launches on the side stream); "
+                                             "in-kernel matrix-pipe shares are in pmc.k1_*"}
         roof["other"] = other
         kname = ("infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)" if d <= 512 else
                  "infonce_wide_scores_kernel + infonce_wide_pv2_kernel (K2 over a wide queue, d > 512: the two passes over the queue; "

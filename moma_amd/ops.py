@@ -428,7 +428,7 @@ def _mha_fast_fwd(items, H, want_lse, qpacks=None):
         m.qpack, m.qpack_scale = (0, 0.0) if qp is None else (qp.buf.data_ptr(), float(qp.scale))
         m.x_dtype = DT_BF16 if x.dtype == torch.bfloat16 else DT_F32
         outs.append((y, qkv16, attn16, lse))
-    with _timed("moma_mha_fwd"):
+    with _timed("moma_mha_fwd" if len(items) == 1 else f"moma_mha_fwd_group{len(items)}"):
         check(lib.moma_mha_fwd_fast(C.cast(mods, C.c_void_p), len(items), N, d, H, _stream()), "moma_mha_fwd_fast")
     return outs
 
