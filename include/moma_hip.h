@@ -14,8 +14,9 @@
  *   - every launch function takes the hipStream_t to enqueue on (as void*), is asynchronous on it and
  *     performs no host synchronisation (safe under hipGraph capture);
  *   - return value: 0 = ok, <0 = argument check failed (MOMA_E_*), >0 = hipError_t of a failed launch;
- *     nothing throws; no mutable global state apart from a once-per-process kernel-attribute setup behind
- *     std::call_once (re-entrant; one host thread per process/GPU);
+ *     nothing throws; no environment variable is read; no mutable global state apart from once-per-process kernel-attribute
+ *     setups (dynamic-LDS opt-ins) behind std::call_once -- they are made for the device that is current at the first call:
+ *     ONE DEVICE PER PROCESS (the DDP model: one host thread per process / GPU); re-entrant within that;
  *   - matrices are row-major and dense unless a leading dimension is given;
  *   - `prec`   : arithmetic of the contractions. MOMA_PREC_F32 = f32-input MFMA (exact fp32 fma chain,
  *                the reference's arithmetic), MOMA_PREC_BF16 = bf16-input MFMA with fp32 accumulate;

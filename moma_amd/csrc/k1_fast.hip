@@ -403,20 +403,25 @@ __global__ __launch_bounds__(256) void k1_pack_kernel(const float* __restrict__ 
     bf16_raw* out_t = pack + 4L * d * d + (is_proj ? 3L * d * d : 0);
     const int r0 = (id / tiles_c) * 32, c0 = (id % tiles_c) * 32;
     const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v = 0.f;
-        if (r0 + tr < rows && c0 + tc + j < d) {
-            v = W[(long)(r0 + tr) * d + c0 + tc + j];
-            out[(long)(r0 + tr) * d + c0 + tc + j] = f32_to_bf16(v);
-        }
-        t[tr][tc + j] = v;
+    // d % 16 == 0 (checked by the entry point): a thread's 4 columns are all inside or all outside, rows are guarded
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + tr < rows && c0 + tc < d) {
+        v = *reinterpret_cast<const float4*>(W + (long)(r0 + tr) * d + c0 + tc);
+        uint2 w;
+        w.x = pack_bf16(v.x, v.y);
+        w.y = pack_bf16(v.z, v.w);
+        *reinterpret_cast<uint2*>(out + (long)(r0 + tr) * d + c0 + tc) = w;
     }
     if (!with_t) return;
+    t[tr][tc] = v.x; t[tr][tc + 1] = v.y; t[tr][tc + 2] = v.z; t[tr][tc + 3] = v.w;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j)                           // out_t[c][r] = W[r][c]: thread -> (column c0 + tr, rows r0 + tc + j)
-        if (c0 + tr < d && r0 + tc + j < rows) out_t[(long)(c0 + tr) * rows + r0 + tc + j] = f32_to_bf16(t[tc + j][tr]);
+    // out_t[c][r] = W[r][c]: thread -> column c0 + tr, rows r0 + tc .. + 3 (rows % 16 == 0: all four inside or outside)
+    if (c0 + tr < d && r0 + tc < rows) {
+        uint2 w;
+        w.x = pack_bf16(t[tc][tr], t[tc + 1][tr]);
+        w.y = pack_bf16(t[tc + 2][tr], t[tc + 3][tr]);
+        *reinterpret_cast<uint2*>(out_t + (long)(c0 + tr) * rows + r0 + tc) = w;
+    }
 }
 
 // =====================================================================================================================
