@@ -980,6 +980,7 @@ def test_effnet_helpers_match_stock_ops(amp):
     ref = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
     new = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
     new.load_state_dict(ref.state_dict())
+    sd_init = [v.clone() for v in ref.state_dict().values()]              # (the runs move the BatchNorm running statistics)
     x = torch.randn(6, 3, 96, 96, device="cuda")
 
     def run(net, hip):
@@ -1018,6 +1019,27 @@ def test_effnet_helpers_match_stock_ops(amp):
             if e > worst:
                 worst, who = e, n0
     assert worst < (0.6 if amp else 2e-2), (who, worst)
+    if amp:
+        # What the loose bf16 bounds above are made of: BOTH bf16 pipelines sit that far from the fp32 network (82 layers of a
+        # random-init net); the library's pipeline must not sit further from fp32 than the stock one does.
+        f32 = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
+        f32.load_state_dict({k: v for k, v in zip(ref.state_dict().keys(), sd_init)})
+        saved = (E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE)
+        E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = "miopen", "aten", "aten", False
+        try:
+            torch.manual_seed(5)
+            feats, logits = f32(x, is_feat=True)
+            (logits.float().square().sum() + feats[-1].float().sum()).backward()
+        finally:
+            E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = saved
+        l32, g32 = logits.detach(), {n: p.grad for n, p in f32.named_parameters() if p.grad is not None}
+        e_stock = ((l0 - l32).abs().max() / l32.abs().max()).item()
+        e_hip = ((l1 - l32).abs().max() / l32.abs().max()).item()
+        assert e_hip < 1.5 * e_stock + 1e-2, ("logits vs fp32", e_hip, e_stock)
+        gs = max(g.abs().max().item() for g in g32.values())
+        ge_stock = max(((p.grad - g32[n]).abs().max() / g32[n].abs().max().clamp_min(3e-2 * gs)).item() for n, p in ref.named_parameters() if n in g32)
+        ge_hip = max(((p.grad - g32[n]).abs().max() / g32[n].abs().max().clamp_min(3e-2 * gs)).item() for n, p in new.named_parameters() if n in g32)
+        assert ge_hip < 1.5 * ge_stock + 2e-2, ("gradients vs fp32", ge_hip, ge_stock)
 
 
 def test_graphed_teacher_forward_matches_eager():

@@ -440,3 +440,52 @@ def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
     rows = contrast.memory[:3 * B].float().cpu().numpy()
     ref_rows = ocontrast.memory[:3 * B].numpy()
     np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
+
+
+def test_mlp_byol_head_runs_the_kd_term_on_the_gpu():
+    """`--head mlp_byol` (reference MoMA/criterion_moco_att.py:269-283: Linear - BatchNorm1d - ReLU - Linear - L2; the class offers
+    it, the reference CLI's choices do not): heads -> atts_q -> one-pass K2 (+ query packed by K1) -> enqueue, backward into the
+    head's BatchNorm1d and Linear weights, against the same chain in plain torch fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.MoMA.mem_moco import MoCo
+    torch.manual_seed(3)
+    B, s_dim, d, K, T = 64, 96, 128, 4096, 0.15
+    opt = argparse.Namespace(head="mlp_byol", s_dim=s_dim, t_dim=s_dim, feat_dim=d, attn="self", moma_prec="bf16", num_heads=4)
+    kd = CMO(opt).cuda().train()
+    assert any(isinstance(m, nn.BatchNorm1d) for m in kd.embed_s.modules())
+    mem = MoCo(d, K, T, queue_dtype=torch.bfloat16, precision="bf16").cuda()
+    queue0 = mem.memory.float().clone()
+    feat_s = torch.randn(B, s_dim, 1, 1, device="cuda")
+    feat_t = torch.randn(B, s_dim, 1, 1, device="cuda")
+    with torch.no_grad():
+        k = kd.atts_k(kd.embed_t(feat_t))
+    qp = mem.qpack(B, d, feat_s.device)
+    q = kd.atts_q(kd.embed_s(feat_s), qpack=qp)
+    loss, _ = mem.forward_fused(q, k, qpack=qp)
+    loss.backward()
+    # plain torch fp32 of the same chain (reference op order)
+    ref = CMO(argparse.Namespace(**{**vars(opt), "moma_prec": "fp32"})).cuda().train()
+    ref.load_state_dict(kd.state_dict())
+
+    def att(m, x):
+        n, c = x.shape
+        h = m.num_heads
+        qkv = nn.functional.linear(x, m.qkv.weight, m.qkv.bias).reshape(n, 3, h, c // h).permute(1, 2, 0, 3)
+        a = ((qkv[0] @ qkv[1].transpose(-2, -1)) * m.scale).softmax(dim=-1)
+        return nn.functional.linear((a @ qkv[2]).transpose(0, 1).reshape(n, c), m.proj.weight, m.proj.bias)
+    rq = att(ref.atts_q, ref.embed_s(feat_s))
+    logits = torch.cat([(rq * k).sum(1, keepdim=True), rq @ queue0.t()], dim=1) / T
+    rloss = nn.functional.cross_entropy(logits, torch.zeros(B, dtype=torch.long, device="cuda"))
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 1e-3 * abs(rloss.item()), (loss.item(), rloss.item())
+    gmax = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
+    for (n0, p0), (n1, p1) in zip(kd.named_parameters(), ref.named_parameters()):
+        if n0.startswith("embed_s.") or n0.startswith("atts_q."):
+            assert p0.grad is not None and p1.grad is not None, n0
+            # relative to the tensor's own scale, with a floor: the bias in front of the BatchNorm1d has a gradient that is zero
+            # up to rounding (the normalisation removes it)
+            err = (p0.grad - p1.grad).abs().max().item() / max(p1.grad.abs().max().item(), 1e-2 * gmax)
+            assert err < 5e-2, (n0, err)
+    assert mem.index == B
