@@ -328,24 +328,29 @@ def main():
     log(f"rank {rank}/{world}: model + queue built; warm-up {a.warmup} steps (first step JIT-compiles MIOpen kernels)")
     import contextlib
     quiet = contextlib.redirect_stdout(sys.stderr)      # stdout carries exactly one JSON line
+    amp_ctx = lambda: torch.autocast("cuda", dtype={"bf16": torch.bfloat16, "fp16": torch.float16}.get(opt.amp), enabled=opt.amp is not None)
+    # ---- untimed: whatever would otherwise run for the FIRST time inside the timed region (round 2's driver line lost 7 % to one
+    # ~65 ms first step).  (1) Every epoch opens with the teacher in eval mode for its first forward (reference
+    # helper/loops_moma.py:227): a (shape, eval) variant the warm-up epoch serves once, eagerly -- ~700 launches of host time.
+    # It is served here until its HIP graph exists (eval-mode BatchNorm: no state changes), on the stream the loop replays on,
+    # and BEFORE the warm-up steps: a graph capture empties the caching allocator's pool (torch.cuda.graph does), which the
+    # warm-up steps then grow back -- captured after them, the first timed step would pay the hipMallocs (seen once: 350 ms).
+    if getattr(opt, "graph_teacher", True) and a.warmup > 0:
+        from moma_amd.helper.graphs import GraphedInference
+        teacher = trainer._graphed_teacher = GraphedInference(model_t)
+        if opt.overlap_teacher:
+            trainer._side_stream = torch.cuda.Stream(device=dev)
+        side = getattr(trainer, "_side_stream", None)
+        x0 = next(iter(loader_w))[0]
+        model_t.eval()
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()), amp_ctx():
+            primed = teacher.prime(x0, is_feat=True)
+        torch.cuda.synchronize()
+        log(f"teacher eval-mode variant graphed before the warm-up: {primed}")
     if a.warmup > 0:
         with quiet:
             train_distill_moma(0, loader_w, module_list, criterion_list, trainer, contrast, optimizer, opt)
-    # ---- still untimed: whatever would otherwise run for the FIRST time inside the timed region (round 2's driver line lost 7 %
-    # to one ~65 ms first step).  (1) every epoch opens with the teacher in eval mode for its first forward (reference
-    # helper/loops_moma.py:227): a (shape, eval) variant the warm-up epoch has served once, eagerly -- ~700 launches of host
-    # time; served here until its HIP graph exists (eval-mode BatchNorm: no state changes).  (2) the instrumented paths
-    # (HIP event creation, the first dispatch that carries events) on calls without side effects.
-    x0 = next(iter(loader_w if a.warmup > 0 else loader_t))[0]
-    teacher = getattr(trainer, "_graphed_teacher", None)
-    if teacher is not None:
-        model_t.eval()
-        side = getattr(trainer, "_side_stream", None)       # capture on the stream the loop replays on (see prime())
-        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()), \
-                torch.autocast("cuda", dtype={"bf16": torch.bfloat16, "fp16": torch.float16}.get(opt.amp), enabled=opt.amp is not None):
-            primed = teacher.prime(x0, is_feat=True)
-        torch.cuda.synchronize()
-        log(f"teacher eval-mode variant graphed before the timed region: {primed}")
+    # (2) the instrumented paths (HIP event creation, the first dispatch that carries events) on calls without side effects
     rec.enabled = True
     kev.enabled = True
     kd = criterion_list[2]
@@ -356,6 +361,7 @@ def main():
             kd.atts_k(qd)
         mem = contrast._bf16_shadow() if (contrast.memory.dtype == torch.float32 and a.moma_prec == "bf16") else contrast.memory
         ops.infonce_fused(qd, qd, mem, contrast.T, a.moma_prec)          # forward only: no enqueue, no state change
+        del qd
     torch.cuda.synchronize()
     rec.events.clear()
     kev.pairs.clear()

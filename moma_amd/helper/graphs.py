@@ -80,11 +80,17 @@ class GraphedInference:
             for _ in range(self.warmup + 1):
                 if self._key(x, is_feat) in self._graphs:
                     break
+                # every call must see an EMPTY autocast weight-cast cache, as it does in the loop (one autocast context per call):
+                # a cast cached by an earlier eager call would be reused during the capture -- the graph would then hold no cast
+                # kernel and read a cached low-precision weight that is freed when the caller's autocast context exits
+                torch.clear_autocast_cache()
                 self(x, is_feat=is_feat)
+            torch.clear_autocast_cache()
             return self._key(x, is_feat) in self._graphs
 
     def _capture(self, key, x, is_feat):
         try:
+            torch.clear_autocast_cache()        # the casts of this forward belong INSIDE the graph (see prime())
             static_x = x.clone()
             graph = torch.cuda.CUDAGraph()
             pending = [(m, m._nbt_pending) for m in self._mods if hasattr(m, "_nbt_pending")]
@@ -95,6 +101,7 @@ class GraphedInference:
             bn_train = [m for m, before in pending if m._nbt_pending != before]
             for m, before in pending:
                 m._nbt_pending = before
+            torch.clear_autocast_cache()        # cached casts made during the capture live in the graph's pool: drop the references
             entry = (graph, static_x, out, bn_train)
             self._graphs[key] = entry
             return entry
