@@ -505,6 +505,37 @@ def test_k2_takes_the_query_prepacked_by_k1(ops, B, d, H):
     assert torch.equal(l1, l2)
 
 
+def test_mha_fast_path_takes_bf16_input_and_follows_raw_pointer_weight_updates(ops):
+    """(a) A bf16 x (the output of a head under bf16 autocast) is consumed as it stands: y, dW equal the fp32-x call on the same
+    values bit for bit, dx comes back in x's dtype.  (b) K4 writes EMA weights through raw pointers (no autograd version bump):
+    ContrastTrainer.momentum_update invalidates the bf16 weight packs of the attention modules it touches."""
+    from moma_amd.MoMA.criterion_moco_att import Attention
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    torch.manual_seed(21)
+    N, d, H = 200, 256, 4
+    att = Attention(d, num_heads=H, qkv_bias=True, precision="bf16").cuda()
+    xb = torch.nn.functional.normalize(torch.randn(N, d, device="cuda")).to(torch.bfloat16)
+    x32 = xb.float().requires_grad_(True)
+    xb = xb.requires_grad_(True)
+    dy = torch.randn(N, d, device="cuda")
+    y32 = att(x32); (y32 * dy).sum().backward()
+    g32 = [p.grad.clone() for p in att.parameters()]
+    for p in att.parameters():
+        p.grad = None
+    y16 = att(xb); (y16 * dy).sum().backward()
+    assert torch.equal(y16, y32) and xb.grad.dtype == torch.bfloat16
+    assert torch.equal(xb.grad, x32.grad.to(torch.bfloat16))
+    for a, b in zip(g32, [p.grad for p in att.parameters()]):
+        assert torch.equal(a, b)
+    # (b)
+    ema = Attention(d, num_heads=H, qkv_bias=True, precision="bf16").cuda()
+    with torch.no_grad():
+        before = ema(x32.detach())
+        ContrastTrainer.momentum_update(att, ema, 0.0)           # m = 0: ema <- att, written by the K4 kernel
+        after = ema(x32.detach())
+    assert not torch.equal(before, after) and torch.equal(after, y32.detach())
+
+
 # ------------------------------------------------------------------------------------------------ ABI
 def test_mha_bitwise_repeatable_gradients(ops):
     """Two forward + backward runs on the same inputs give bit-identical outputs and weight gradients in both policies
