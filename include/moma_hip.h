@@ -132,12 +132,14 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
  * 16 bytes per unit, rows padded to a multiple of 128 with zeros: moma_infonce_qpack_bytes(B, d) bytes (0 = this width takes
  * no pre-packed query: d must be 128 / 256 / 384 / 512).  The producer of q writes it -- moma_mha_fwd_fast does when asked
  * (moma_mha_module_t.qpack) -- and the call then runs no pre-pack launch.  q itself (fp32) is still read for the exact positive
- * logit.  The results are bit-identical to moma_infonce_fused_ex on the same q. */
+ * logit.  The results are bit-identical to moma_infonce_fused_ex on the same q.
+ * ev_call_end (hipEvent_t or NULL): recorded when the LAST kernel of the call has finished (on its dispatch), so that
+ * ev_begin .. ev_call_end spans the kernels of the call without the latency of event packets around it. */
 size_t moma_infonce_qpack_bytes(int B, int d);
 int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
                          float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
                          void* workspace, size_t workspace_bytes, int qdtype, int prec,
-                         moma_stream_t stream, void* ev_begin, void* ev_end);
+                         moma_stream_t stream, void* ev_begin, void* ev_end, void* ev_call_end);
 
 /* Several InfoNCE terms over queues of the same shape in ONE sweep -- replaces the 2 / 4 `_compute_logit` calls + CrossEntropy of
  * the dual-queue memories MoCoST.forward / MoCoSSTT.forward (MoMA/mem_moco.py:165-253):

@@ -148,14 +148,15 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
                           size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin,
                           void* ev_end) {
     return moma_infonce_fused_q(q, nullptr, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, workspace_bytes,
-                                qdtype, prec, stream, ev_begin, ev_end);
+                                qdtype, prec, stream, ev_begin, ev_end, nullptr);
 }
 
 size_t moma_infonce_qpack_bytes(int B, int d) { return infonce_qpack_bytes(B, d); }
 
 int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
                          float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
-                         size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end) {
+                         size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end,
+                         void* ev_call_end) {
     if (!q || !k || !queue || !loss_rows || !lse || !top1 || !workspace) return MOMA_E_NULL;
     if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
@@ -166,10 +167,14 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
         return q_packed && misaligned(q_packed, 16) ? MOMA_E_ALIGN : MOMA_E_UNSUPPORTED;
     if (infonce_flash_supported(B, d, K, qdtype, prec))
         return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,
-                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed));
+                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed, (hipEvent_t)ev_call_end));
     if (infonce_f32_flash_supported(B, d, K, qdtype, prec))      // exact fp32, fp32 queue: one pass, no [B,K+1] logits
-        return hip_rc(launch_infonce_f32_flash(q, k, (const float*)queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, st,
-                                               (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
+    {
+        const int rc = hip_rc(launch_infonce_f32_flash(q, k, (const float*)queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, st,
+                                                       (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
+        if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
+        return rc;
+    }
     // staged path (any shape, exact fp32 available): logits -> row reduction -> gradient product
     float* logits = (float*)workspace;
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, st);
@@ -177,8 +182,9 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, st);
     if (rc != MOMA_OK) return rc;
     MOMA_TRY(launch_infonce_rows(logits, B, K + 1, loss_rows, lse, top1, dq != nullptr, st));
-    if (dq) return moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);
-    return MOMA_OK;
+    if (dq) rc = moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);
+    if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
+    return rc;
 }
 
 size_t moma_infonce_fused_multi_workspace_bytes(int n_terms, int B, int d, int K, int qdtype, int prec) {

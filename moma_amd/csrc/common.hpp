@@ -90,7 +90,7 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K);
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                                const void* q_packed = nullptr);
+                                const void* q_packed = nullptr, hipEvent_t ev_call_end = nullptr);
 size_t infonce_qpack_bytes(int B, int d);
 bool infonce_multi_supported(int n_terms, int B, int d, int K, int qdtype, int prec);
 size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K);

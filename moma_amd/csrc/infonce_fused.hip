@@ -1635,7 +1635,7 @@ size_t infonce_qpack_bytes(int B, int d) {
 // producer of q (K1's proj epilogue, k1_fast.hip) -- the pre-pack launch is skipped.
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed) {
+                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed, hipEvent_t ev_call_end) {
     const FlashPlan p = plan(B, K);
     if (p.nchunk > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;
     const size_t rows = (size_t)p.nchunk * p.Bpad;
@@ -1731,8 +1731,9 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         {
             int tpb = 4;                                           // (measured at d = 1280: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call)
             const int nty = dq ? (d / 32 + tpb - 1) / tpb : 1;
-            hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, nty), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk, p.Bpad,
-                               o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, (long)(slab_bytes / 16), cg, tpb, wide_ref);
+            hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, nty), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+                                  d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq,
+                                  (long)(slab_bytes / 16), cg, tpb, wide_ref);
         }
         return hipGetLastError();
     }
@@ -1755,8 +1756,9 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_FLASH_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, q, k, B, d, inv_T, p.nchunk,
-                       p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
+    // (ev_call_end rides on the combine's dispatch: ev_begin .. ev_call_end spans the call's kernels, dispatch to dispatch)
+    hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,
+                          k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
     return hipGetLastError();
 }
 

@@ -115,7 +115,6 @@ struct K1Job {
     float* dpart; const bf16_raw* R; long ldr;   // KC, nullable: dpart[(col / 16) * M + row] = sum over the 16 columns of C * R
     bf16_raw* qpack; float qpack_scale;          // KC, nullable: K2's packed-Q image of C (infonce_fused.hip: infonce_qpack_kernel)
     float* colsum;            // KS, nullable [M]: sum_k A[k, m] (the bias gradient beside dW)
-    int wide;                 // (reserved)
     int tiles_n, tile0, tile_end;
 };
 struct K1Jobs {
@@ -247,14 +246,25 @@ __device__ __forceinline__ void kc_body(const K1Job& J, int tile, char* smem) {
     }
 }
 
-// two adjacent columns of token `tok` as a packed bf16 pair (lo = even column)
+// two adjacent columns of token `tok`: the values as stored (the column sums -- bias gradients -- add these: an fp32 operand
+// is summed in fp32, like the reference's dy.sum(0)) and as a packed bf16 pair for the MFMA (lo = even column)
+struct KsPair {
+    float lo, hi;
+    unsigned packed;
+};
 template <bool F32>
-__device__ __forceinline__ unsigned ks_load_pair(const void* base, long ld, int tok, int col) {
+__device__ __forceinline__ KsPair ks_load_pair(const void* base, long ld, int tok, int col) {
+    KsPair p;
     if constexpr (F32) {
         const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(base) + (long)tok * ld + col);
-        return pack_bf16(v.x, v.y);
+        p.lo = v.x; p.hi = v.y;
+        p.packed = pack_bf16(v.x, v.y);
+    } else {
+        p.packed = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_raw*>(base) + (long)tok * ld + col);
+        p.lo = __uint_as_float(p.packed << 16);
+        p.hi = __uint_as_float(p.packed & 0xffff0000u);
     }
-    return *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_raw*>(base) + (long)tok * ld + col);
+    return p;
 }
 
 template <bool AF32, bool BF32>
@@ -279,13 +289,6 @@ __device__ __forceinline__ void ks_body(const K1Job& J, int tile, char* smem) {
     float cs0 = 0.f, cs1 = 0.f;
     constexpr int CH = 4;                                   // k-steps in flight
     auto step = [&](const unsigned (&da)[8], const unsigned (&db)[8]) {
-        if (want_cs) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                cs0 += __uint_as_float(da[j] << 16);
-                cs1 += __uint_as_float(da[j] & 0xffff0000u);
-            }
-        }
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
         u32x4 ae, ao, be, bo;
 #pragma unroll
@@ -310,8 +313,10 @@ __device__ __forceinline__ void ks_body(const K1Job& J, int tile, char* smem) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int tok = (sb + c0 + s) * 16 + 8 * h + j;
-                da[s][j] = ks_load_pair<AF32>(J.A, J.lda, tok, ma);
-                db[s][j] = ks_load_pair<BF32>(J.B, J.ldb, tok, nb);
+                const KsPair pa = ks_load_pair<AF32>(J.A, J.lda, tok, ma);
+                da[s][j] = pa.packed;
+                db[s][j] = ks_load_pair<BF32>(J.B, J.ldb, tok, nb).packed;
+                if (want_cs) { cs0 += pa.lo; cs1 += pa.hi; }
             }
 #pragma unroll
         for (int s = 0; s < CH; ++s) step(da[s], db[s]);
@@ -321,14 +326,12 @@ __device__ __forceinline__ void ks_body(const K1Job& J, int tile, char* smem) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int tok = min((sb + c0) * 16 + 8 * h + j, J.K - 1);
-            da[j] = ks_load_pair<AF32>(J.A, J.lda, tok, ma);
-            db[j] = ks_load_pair<BF32>(J.B, J.ldb, tok, nb);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
             const bool live = (sb + c0) * 16 + 8 * h + j < J.K;
-            da[j] = live ? da[j] : 0u;
-            db[j] = live ? db[j] : 0u;
+            const KsPair pa = ks_load_pair<AF32>(J.A, J.lda, tok, ma);
+            const unsigned pb = ks_load_pair<BF32>(J.B, J.ldb, tok, nb).packed;
+            da[j] = live ? pa.packed : 0u;
+            db[j] = live ? pb : 0u;
+            if (want_cs && live) { cs0 += pa.lo; cs1 += pa.hi; }
         }
         step(da, db);
     }
@@ -803,7 +806,6 @@ int finish_jobs(K1Jobs& js) {
     int t = 0, lds = GEMM_LDS;
     for (int i = 0; i < js.n; ++i) {
         K1Job& j = js.j[i];
-        j.wide = 0;
         int TM = 64, TN = 64;
         if (j.kind == 0) {
             TM = 32;

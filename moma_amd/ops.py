@@ -68,8 +68,8 @@ def set_event_recorder(rec) -> None:
     _EVENT_RECORDER = rec
 
 
-# Optional (bench.py): a callable returning a (hipEvent_t, hipEvent_t) pair of raw handles that the library records
-# around the dominant kernel of the next moma_infonce_fused call (see moma_infonce_fused_ex).
+# Optional (bench.py): a callable returning three raw hipEvent_t handles that the library records on the dispatches of the next
+# moma_infonce_fused call: begin / end of its dominant kernel and end of its last kernel (see moma_infonce_fused_q).
 _KERNEL_EVENTS = None
 
 
@@ -277,11 +277,11 @@ class _InfoNCEFused(torch.autograd.Function):
         qd = _qdtype(queue)
         ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        ev0, ev1 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None)
+        ev0, ev1, ev2 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None, None)
         with _timed("moma_infonce_fused"):
             check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
                                            _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec,
-                                           _stream(), C.c_void_p(ev0), C.c_void_p(ev1)),
+                                           _stream(), C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
                   "moma_infonce_fused")
         if need_grad:
             ctx.save_for_backward(dq)
