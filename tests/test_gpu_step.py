@@ -153,13 +153,16 @@ def test_loop_bf16_policy_matches_reference_trace_big_queue(golden_dir, ci, queu
                                rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize("queue_dtype,overlap", [("bf16", True), ("fp32", True), ("bf16", False)])
-def test_loop_bf16_policy_matches_reference_trace_bench_batch(golden_dir, queue_dtype, overlap):
+@pytest.mark.parametrize("prec,queue_dtype,overlap", [("bf16", "bf16", True), ("bf16", "fp32", True), ("bf16", "bf16", False),
+                                                      ("fp32", "fp32", True)])
+def test_loop_bf16_policy_matches_reference_trace_bench_batch(golden_dir, prec, queue_dtype, overlap):
     """The benchmark's KD configuration at the benchmark's BATCH, tied to the reference at loop level (G5c: B = 256 -- two
     128-row blocks in the one-pass K2, eight key tiles per K1 workgroup --, K = 65536, --head mlp, d = 512, lr 0.002, 5 steps):
     bf16 policy (one-pass K2 fed with the query packed by atts_q's proj epilogue, K1 fast path with atts_k + atts_queue as one
     group, K3, K4), teacher side on the second stream + HIP graphs when overlap is on.  resnet8 backbones stay fp32.
-    North-star tolerance on EVERY step: per-step loss_kd within 1e-3 relative of the reference; pointer exact."""
+    North-star tolerance on EVERY step: per-step loss_kd within 1e-3 relative of the reference; pointer exact.
+    prec = fp32: the reference's own arithmetic -- K1 staged on f32-input MFMA, K2 as ONE pass over the fp32 queue on the f32 MFMA
+    (infonce_f32.hip) -- at 1e-4."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from tests.g5b_util import K_BIG, batches, big_queue, fill_attention_, sd
@@ -176,7 +179,7 @@ def test_loop_bf16_policy_matches_reference_trace_bench_batch(golden_dir, queue_
     d, B, steps, lr = int(g[p + "feat_dim"]), int(g[p + "B"]), int(g[p + "steps"]), float(g[p + "lr"])
     opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K_BIG, nce_t=0.15,
                              alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False,
-                             print_freq=1000, batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16",
+                             print_freq=1000, batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec=prec,
                              queue_dtype=queue_dtype, moma_fused=True, trace=[], overlap_teacher=overlap,
                              graph_teacher=overlap)
     dev = torch.device("cuda", 0)
@@ -200,12 +203,13 @@ def test_loop_bf16_policy_matches_reference_trace_bench_batch(golden_dir, queue_
     assert [t[1] for t in opt.trace] == [int(v) for v in g[p + "index"]]
     ref_kd, ref_loss = g[p + "loss_kd"], g[p + "loss"]
     print("loss_kd rel err:", (np.abs(kds - ref_kd) / np.abs(ref_kd)).round(6), " total |err|:", np.abs(losses - ref_loss).round(5))
-    np.testing.assert_allclose(kds, ref_kd, rtol=1e-3, atol=0)           # north star, every step
-    np.testing.assert_allclose(losses, ref_loss, rtol=1e-3, atol=0)
+    tol = 1e-3 if prec == "bf16" else 1e-4
+    np.testing.assert_allclose(kds, ref_kd, rtol=tol, atol=0)            # north star (bf16), every step
+    np.testing.assert_allclose(losses, ref_loss, rtol=tol, atol=0)
     ids = torch.from_numpy(g[p + "memory_rows_ids"]).to(dev)
     rows = contrast.memory[ids].float().cpu().numpy()
     ref_rows = g[p + "memory_rows_final"]
-    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
+    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=(3e-2 if prec == "bf16" else 1e-4) * np.abs(ref_rows).max())
     np.testing.assert_allclose(kd.atts_q.proj.weight.detach()[:8, :8].cpu().numpy(), g[p + "kd_final.atts_q.proj.weight_8x8"],
                                rtol=0, atol=2e-3)
 
