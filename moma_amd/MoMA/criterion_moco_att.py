@@ -4,7 +4,7 @@ Drop-in for the reference's MoMA/criterion_moco_att.py (`Normalize` :12-18, `Fla
 `Attention` :141-167, `CMO` :236-338): same constructor arguments, sub-module names and state-dict keys
 (`atts_q.qkv.weight`, `atts_q.proj.bias`, `embed_s.1.weight`, ...).  `Attention.forward` -- the chain
 Linear -> reshape/permute -> q k^T * scale -> softmax -> attn v -> transpose -> Linear -- runs in the HIP
-library (moma_mha_fwd / moma_mha_bwd, K1).  Heads (Flatten / Linear / ReLU / L2-normalise on [B,s_dim])
+library (K1: moma_mha_fwd_fast / moma_mha_bwd_fast under the bf16 policy, moma_mha_fwd / moma_mha_bwd under exact fp32).  Heads (Flatten / Linear / ReLU / L2-normalise on [B,s_dim])
 stay stock torch ops, as the scope table allows.
 """
 import torch

@@ -239,7 +239,8 @@ class QPack:
         self.buf, self.shape, self.scale, self.src = None, None, None, None
 
     def prepare(self, B: int, d: int, T: float, device):
-        """-> (buffer, scale) for Attention.forward(x, qpack=...), or None when K2 takes no pre-packed query at this width."""
+        """-> this holder, ready to be handed to Attention.forward(x, qpack=...) and then to infonce_fused(..., qpack=...); None
+        when K2 takes no pre-packed query at this width (d not in {128, 256, 384, 512})."""
         lib = _lib.load()
         nbytes = lib.moma_infonce_qpack_bytes(B, d)
         if nbytes == 0:
