@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
         dma_tile(t0, 0);
         for (int t = t0; t < t1; ++t) {
             const int b = (t - t0) & 1;
-            // (issuing the next tile's 16 pieces one per group of four score MFMAs instead of here was measured slower -- 389 vs
-            //  377 us with dq, 233 vs 210 forward-only: the per-piece address arithmetic lands between the MFMAs)
+            // (measured and not taken: the next tile's 16 pieces issued one per group of four score MFMAs instead of here -- 389 vs
+            //  377 us with dq, 233 vs 210 forward-only; the pieces by inline asm with one base + one xor each instead of the
+            //  builtin's ~12 instructions -- 384 / 212 us, no change: the DMA issue is not what the tile waits for)
             if (t + 1 < t1) {
                 dma_tile(t + 1, b ^ 1);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
