@@ -52,8 +52,15 @@ class Attention(nn.Module):
         self._pack = ops.MhaPack()          # bf16 weight copies of the fast path (not a parameter, not in the state dict)
 
     def invalidate_pack(self):
-        """Call after writing the weights through anything that bypasses autograd's version counters."""
+        """Call after writing the weights through anything that bypasses autograd's version counters: a raw-pointer kernel,
+        or in-place arithmetic on `weight.data` (the reference's own EMA idiom, `p.data.mul_(m).add_(...)`: `.data` carries
+        a version counter of its own).  optimizer.step(), load_state_dict(), .to() / .cuda() and ContrastTrainer.momentum_update
+        are followed without it."""
         self._pack.invalidate()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pack.invalidate()
+        super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, qpack=None):
         if x.dim() != 2:
