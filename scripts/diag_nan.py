@@ -28,7 +28,7 @@ if variant == "nogroup":
 if variant == "nooverlap":
     opt.overlap_teacher = False
 opt.trace = []
-for ep, n in ((0, 5), (1, 6)):
+for ep, n in ((0, 5), (1, int(os.environ.get("DIAG_STEPS", 6)))):
     loader = SyntheticLoader(n, a.batch_size, a.image_size, a.n_cls, 12345, dev)
     train_distill_moma(ep, loader, module_list, criterion_list, trainer, contrast, optimizer, opt)
     torch.cuda.synchronize()
