@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--model_t", default=None, help="teacher architecture (default: the student's; a different one keeps the "
                                                    "teacher frozen -- BASELINE configs[4]: --model ResNet50 --model_t vit_base_patch16_224)")
     p.add_argument("--n_cls", type=int, default=4)
+    p.add_argument("--num_heads", type=int, default=4, help="heads of the batch-token attention modules (reference: 4; BASELINE configs[2]: 8)")
     p.add_argument("--moma_prec", default="bf16", choices=["fp32", "bf16"])
     p.add_argument("--queue_dtype", default="bf16", choices=["fp32", "bf16"])
     p.add_argument("--amp", default="bf16", choices=["none", "bf16", "fp16"])
@@ -203,7 +204,7 @@ def make_opt(a, rank, world):
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=0.05, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
-        shuffle_bn="per_rank", num_heads=4,
+        shuffle_bn="per_rank", num_heads=a.num_heads,
         # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
         overlap_teacher=a.overlap_teacher and (os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1" or
                                                os.environ.get("MOMA_BENCH_FORCE_OVERLAP") == "1"))
@@ -469,11 +470,11 @@ def main():
             "ms_first_step": round(step_gpu[0], 3) if step_gpu else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: {a.model} student+teacher" if (a.model_t or a.model) == a.model else
+            "config": {"workload": (f"BASELINE configs[{2 if a.model.startswith('vit_small') else 1}]: {a.model} student+teacher" if (a.model_t or a.model) == a.model else
                                     f"BASELINE configs[4], single-GPU form: {a.model} student <- {a.model_t} teacher (frozen: architectures differ)") +
                                    f" (random init), synthetic "
                                    f"{a.image_size}x{a.image_size} RGB, per-GPU batch {a.batch_size}, queue K={a.nce_k} "
-                                   f"x d={d} ({a.queue_dtype}), head={a.head}, attn=self (4 heads), -c 1 -d 1 -b 1, "
+                                   f"x d={d} ({a.queue_dtype}), head={a.head}, attn=self ({a.num_heads} heads), -c 1 -d 1 -b 1, "
                                    f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp} (BN+SiLU / depthwise / SE on the library's helper "
                                    f"kernels: MOMA_BN={os.environ.get('MOMA_BN', 'hip')} MOMA_DW={os.environ.get('MOMA_DW', 'hip')} "
                                    f"MOMA_SE={os.environ.get('MOMA_SE', 'hip')}), KD kernels {a.moma_prec}",
