@@ -12,7 +12,7 @@ from moma_amd.helper.loops_moma import train_distill_moma
 from moma_amd.dataset.synthetic import SyntheticLoader
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "default"
-sys.argv = sys.argv[:1]
+sys.argv = sys.argv[:1] + os.environ.get("DIAG_ARGS", "").split()
 a = bench.parse()
 dev = torch.device("cuda", 0)
 opt = bench.make_opt(a, 0, 1)
