@@ -759,14 +759,20 @@ __global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __res
 // 3 phase buffers): x accumulates over the NSEG/PSEG phases of a tile; behind the tile's last phase the wave updates its
 // online (max, sum) per lane half and stores P~ = bf16(2^(x - r)) in A-operand order for the P.K pass (below: `sweep`).
 // Leaves per (chunk, row): m = true maximum, l = sum 2^(x - m), max = m -- the partial format of the one-pass kernel -- and r.
-template <int NSEG, int PSEG>
+// QP = 2 (rows of 2 * NSEG segments, e.g. d = 2048 = 2 x 8): the Q block of a wave is twice the register file, so the workgroup
+// sweeps its key chunk once per HALF of the columns -- sweep A with Q[:, :d/2] resident leaves the partial scores (fp32, tile
+// register order, 4 KiB per wave and tile) in the scratch `xq`, sweep B with Q[:, d/2:] resident starts every tile's accumulator
+// from them (requested one phase ahead) and finishes the tile as above.  The partials are written and re-read by the same wave
+// (L2-resident: 16 KiB per workgroup and tile against 128 KiB of keys); the keys cross L2 -> CU once, as for QP = 1.
+template <int NSEG, int PSEG, int QP = 1>
 __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4* __restrict__ qpack,
                                                                      const bf16_raw* __restrict__ queue, int B, int K, int nbt,
                                                                      int nchunk, int tiles_per_chunk, int Bpad,
                                                                      uint4* __restrict__ ps, float* __restrict__ m_part,
                                                                      float* __restrict__ l_part, float* __restrict__ x_part,
-                                                                     float* __restrict__ r_part) {
+                                                                     float* __restrict__ r_part, uint4* __restrict__ xq) {
     static_assert(NSEG % PSEG == 0 && PSEG <= 6, "phases tile the row; 3 phase buffers fit 160 KiB");
+    static_assert(QP == 1 || QP == 2, "one or two register passes of Q");
     constexpr int KS = NSEG * 8;                    // k-steps of a complete score tile
     constexpr int NA = KS < 64 ? KS : 64;           // Q fragments kept in AGPRs
     constexpr int NV = KS - NA;                     // ... and in VGPRs
@@ -795,15 +801,15 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
     const int ntiles = (K + KT - 1) / KT;
     const int t0 = chunk * tiles_per_chunk;
     const int t1 = min(t0 + tiles_per_chunk, ntiles);
-    const unsigned pitch = NSEG * 256;
+    const unsigned pitch = NSEG * QP * 256;
     const DmaLane dl = dma_lane_terms<128>(lane, wave, pitch);
     const long prow = (long)chunk * Bpad + bt * QROWS_WG + wave * 32;
 
-    // ---- Q: inline-asm loads (counted by hand: LDS-DMA and ordinary loads share vmcnt), AGPR part first
+    // ---- Q (of column half `qp`): inline-asm loads (counted by hand: LDS-DMA and ordinary loads share vmcnt), AGPR part first
     bf16x8 qa[NA];
     bf16x8 qv[NV > 0 ? NV : 1];
-    {
-        const char* qb = reinterpret_cast<const char*>(qpack + ((long)(bt * 4 + wave) * KS) * 64 + lane);
+    auto load_q = [&](int qp) __attribute__((always_inline)) {
+        const char* qb = reinterpret_cast<const char*>(qpack + ((long)(bt * 4 + wave) * (KS * QP) + qp * KS) * 64 + lane);
 #pragma unroll
         for (int f = 0; f < KS; ++f) {
             if (f < NA)
@@ -811,12 +817,31 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             else
                 asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qv[f >= NA ? f - NA : 0]) : "v"(qb + (f >> 2) * 4096), "n"((f & 3) * 1024) : "memory");
         }
-    }
+    };
+    auto pin_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < NA; ++f) asm volatile("" : "+a"(qa[f]));
+#pragma unroll
+        for (int f = 0; f < NV; ++f) asm volatile("" : "+v"(qv[f]));
+    };
+    load_q(0);
+    int colb = 0;                                    // byte offset of the resident column half in a key row (wave-uniform)
+    // ---- partial scores of tile t (QP = 2): 4 x 16 B per lane, lane-contiguous kilobytes
+    f32x4 xn[4];
+    auto xq_ptr = [&](int t) __attribute__((always_inline)) {
+        return reinterpret_cast<char*>(xq) + (((long)(bt * 4 + wave) * ((K + KT - 1) / KT) + t) * 4096 + lane * 16);
+    };
+    auto load_x = [&](int t) __attribute__((always_inline)) {
+        const char* xb = xq_ptr(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xn[i]) : "v"(xb), "n"(i * 1024) : "memory");
+    };
     // ---- LDS-DMA of phase (tile, p) into a phase buffer: piece i of this wave = segment i>>1, row group (i&1)*4 + wave
     auto dma_piece_ph = [&](int i, int tile, int p, char* buf) __attribute__((always_inline)) {
         const int sg = i >> 1, rg = (i & 1) * 4 + wave;
         const long key0 = (long)tile * KT;
-        const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (p * PSEG + sg) * 256;
+        const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (colb + (p * PSEG + sg) * 256);
         unsigned off = dl.term;
         if (key0 + KT > K) {                        // queue's last, partial tile: clamp rows past K (masked later)
             const int rl = lane >> 4;
@@ -858,13 +883,13 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
         }
     };
     float m_run = NEG_BIG, l_run = 0.f;
-    // Q and phase 0 have landed (phase 1 may stay in flight)
-    if (nph_total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int f = 0; f < NA; ++f) asm volatile("" : "+a"(qa[f]));
-#pragma unroll
-    for (int f = 0; f < NV; ++f) asm volatile("" : "+v"(qv[f]));
+    // Q (and, before sweep B, the first tile's partial scores) and phase 0 have landed (phase 1 may stay in flight)
+    auto first_phase_landed = [&]() __attribute__((always_inline)) {
+        if (nph_total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    first_phase_landed();
+    pin_q();
     __builtin_amdgcn_s_barrier();
 
     // The scores leave as P~ = bf16(2^(x - r)) in MFMA A-operand order (half the bytes of fp32 scores, and pass 2 needs no
@@ -873,8 +898,11 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
     // overflow) makes the workgroup repeat its chunk with r = ceil(true row maximum), which cannot (rare, workgroup-uniform).
     float r_ref = 0.f;
     int ovf = 0;
-    auto sweep = [&](auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
+    // KIND 0: sweep A of QP = 2 (partial scores -> xq);  1: the (first) finishing sweep;  2: its repeat with r = true maxima
+    auto sweep = [&](auto kind_tag) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool FIRST = KIND == 1;
+    constexpr bool FROM_X = QP == 2 && KIND != 0;    // accumulators start from the other half's partial scores
     int bi = 0;                                      // buffer of the current phase
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
@@ -893,6 +921,9 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             }
 #pragma unroll
             for (int j = 0; j < RD; ++j) rd(j);
+            // (sweep B: the next tile's partial scores, requested in front of this phase's refill so that the wait at the phase's
+            //  end covers them; their registers were consumed by this tile's first MFMA a phase ago)
+            if (FROM_X && p == NPH - 1 && t + 1 < t1) load_x(t + 1);
             // refill requested at the TOP of the phase: the kernel is bound by (bytes in flight) / (memory latency), and pieces of
             // phase g+2 spread over the MFMAs of phase g are in flight half a phase less (measured: 69 -> 64 us forward-only)
             if (refill) {
@@ -906,7 +937,11 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
                 const int ahead = (PSTEPS - 1 - j) < (RD - 1) ? (PSTEPS - 1 - j) : (RD - 1);
                 wait_lgkm(ahead);
                 __builtin_amdgcn_sched_barrier(0);
-                if (f == 0)
+                if (f == 0 && FROM_X) {
+                    const f32x16 xin = {xn[0][0], xn[0][1], xn[0][2], xn[0][3], xn[1][0], xn[1][1], xn[1][2], xn[1][3],
+                                        xn[2][0], xn[2][1], xn[2][2], xn[2][3], xn[3][0], xn[3][1], xn[3][2], xn[3][3]};
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(x) : "v"(kf[j % RD]), "a"(qa[0]), "v"(xin));
+                } else if (f == 0)
                     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(x) : "v"(kf[j % RD]), "a"(qa[0]));
                 else if (f < NA)
                     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[j % RD]), "a"(qa[f < NA ? f : 0]));
@@ -918,6 +953,14 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             if (p == NPH - 1) {
                 // ---- the tile's scores are complete (the MFMA result needs its wait states before a VALU reads it)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x));
+                if constexpr (KIND == 0) {
+                    char* xb = xq_ptr(t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = {x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" :: "v"(xb), "v"(v), "n"(i * 1024) : "memory");
+                    }
+                } else {
                 if ((t + 1) * KT > K) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -950,22 +993,40 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
                 uint4* pd = ps + (((long)(bt * 4 + wave) * ntiles + t) * 64 + lane) * 2;
                 pd[0] = w0;
                 pd[1] = w1;
+                }
             }
             // the next phase must have landed.  Certainly younger than its pieces: this phase's refill pieces and, behind a tile's
             // last phase, the 4 score stores just issued (the previous tile's stores may be younger too: not counted, i.e.
             // waited for -- they are a phase old)
             if (refill) {
-                if (p == NPH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP + 2) : "memory");
+                if (p == NPH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP + (KIND == 0 ? 4 : 2)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (FROM_X && p == NPH - 1) asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
             __builtin_amdgcn_s_barrier();
             bi = bi == 2 ? 0 : bi + 1;
         }
     }
     };
-    sweep(std::true_type{});
+    // (sweep B's start: the other half of Q over the same registers, the first tile's partial scores, the first two phases)
+    auto start_sweep_b = [&](bool reload_q) __attribute__((always_inline)) {
+        if (reload_q) load_q(1);
+        load_x(t0);
+        issue_first_phases();
+        first_phase_landed();
+        if (reload_q) pin_q();
+        asm volatile("" : "+v"(xn[0]), "+v"(xn[1]), "+v"(xn[2]), "+v"(xn[3]));
+        __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (QP == 2) {
+        sweep(std::integral_constant<int, 0>{});     // (ends with vmcnt(0) + barrier: the partial scores are written)
+        colb = NSEG * 256;
+        asm volatile("" : "+s"(colb));
+        start_sweep_b(true);
+    }
+    sweep(std::integral_constant<int, 1>{});
     // ---- per (chunk, row): the two lane halves hold disjoint keys of the same row
     const float mo = other_half(m_run), lo = other_half(l_run);
     const float M = fmaxf(m_run, mo);
@@ -978,11 +1039,14 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
         if ((wflag[0] | wflag[1] | wflag[2] | wflag[3]) != 0) {
             r_ref = ceilf(M);                                                    // true row maximum of the chunk
             __syncthreads();
-            issue_first_phases();
-            if (nph_total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            sweep(std::false_type{});
+            if constexpr (QP == 2) {
+                start_sweep_b(false);                                            // (Q[:, d/2:] is still resident, xq still holds sweep A)
+            } else {
+                issue_first_phases();
+                first_phase_landed();
+                __builtin_amdgcn_s_barrier();
+            }
+            sweep(std::integral_constant<int, 2>{});
         }
     }
     if (h == 0) {
@@ -1585,6 +1649,7 @@ FlashPlan plan(int B, int K, int nterms = 1) {
 
 constexpr int WIDE_PV2_LDS = (MOMA_K2_WPV_SD + 1) * 16384 + 8 * 8 * 64 * 4;     // ring of (32 keys x 256 columns) slots + the scale-factor table
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
+static bool two_qpass_dim(int d) { return d == 2048; }                           // scores in two register passes of Q (8 + 8 segments)
 static bool slab_dim(int d) { return d > 512 && d <= 4096 && d % 128 == 0; }     // column slabs of 512 / 384 / 256 / 128
 
 bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec) {
@@ -1600,6 +1665,7 @@ size_t infonce_flash_workspace_bytes(int B, int d, int K) {
     const int nslab = (d + 511) / 512;                       // one partial buffer per column slab
     size_t bytes = (size_t)nslab * rows * ds * 2 + 4 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
     if (d > 512) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * sizeof(float) + 512;      // score / P scratch
+    if (two_qpass_dim(d)) bytes += (size_t)p.Bpad * ((K + KT - 1) / KT) * KT * 2 + 512;         // P behind the partial scores
     return bytes;
 }
 
@@ -1620,8 +1686,9 @@ void set_lds_attrs() {
 #define MOMA_SET_WIDE(NS, PS) (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<NS, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PS * 8192 + 16)
     MOMA_SET_WIDE(5, 5); MOMA_SET_WIDE(6, 6); MOMA_SET_WIDE(8, 4); MOMA_SET_WIDE(10, 5); MOMA_SET_WIDE(12, 6);
 #undef MOMA_SET_WIDE
+    (void)hipFuncSetAttribute((const void*)infonce_wide_scores_kernel<8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 8192 + 16);
 #define MOMA_SET_WPV(NS) (void)hipFuncSetAttribute((const void*)infonce_wide_pv2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_PV2_LDS)
-    MOMA_SET_WPV(5); MOMA_SET_WPV(6); MOMA_SET_WPV(8); MOMA_SET_WPV(10); MOMA_SET_WPV(12);
+    MOMA_SET_WPV(5); MOMA_SET_WPV(6); MOMA_SET_WPV(8); MOMA_SET_WPV(10); MOMA_SET_WPV(12); MOMA_SET_WPV(16);
 #undef MOMA_SET_WPV
 }
 }  // namespace
@@ -1661,22 +1728,25 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         qpack = (uint4*)(((uintptr_t)((char*)o_part + (size_t)nslab * slab_bytes) + 255) & ~(uintptr_t)255);
         float* xs = (float*)(((uintptr_t)((char*)qpack + (size_t)p.Bpad * d * 2) + 255) & ~(uintptr_t)255);
         const int ntiles = (K + KT - 1) / KT;
+        // (two register passes of Q: the fp32 partial scores take the scratch, P~ sits behind them)
+        uint4* pscr = two_qpass_dim(d) ? (uint4*)(((uintptr_t)(xs + (size_t)p.Bpad * ntiles * KT) + 255) & ~(uintptr_t)255) : (uint4*)xs;
         auto slab_width = [&](int col0) { const int rem = d - col0; return rem >= 512 ? 512 : rem; };   // 512.., then 384/256/128
         // (the measurement events span the passes over the queue -- scores and P.K -- like the one-pass path, where they span the
         //  flash kernel: the Q pre-pack in front and the combine behind are outside in both)
         const int nseg = d / 128;
         bool ev_on_dispatch = false;                           // the two-pass kernels carry the measurement events on their dispatches
-#define MOMA_WIDE_SCORES(NS, PS, DD)                                                                                          \
+#define MOMA_WIDE_SCORES(NS, PS, DD, QPS)                                                                                        \
         do {                                                                                                                  \
             hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((p.Bpad / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, p.Bpad / 32); \
-            hipExtLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS>), grid, block, 3 * PS * 8192 + 16, st, ev_begin, dq ? (hipEvent_t) nullptr : ev_end, 0, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, (uint4*)xs, m_part, l_part, x_part, r_part); \
+            hipExtLaunchKernelGGL((infonce_wide_scores_kernel<NS, PS, QPS>), grid, block, 3 * PS * 8192 + 16, st, ev_begin, dq ? (hipEvent_t) nullptr : ev_end, 0, qpack, qu, B, K, p.nbt, p.nchunk, p.tiles_per_chunk, p.Bpad, pscr, m_part, l_part, x_part, r_part, (uint4*)xs); \
             ev_on_dispatch = true;                                                                                            \
         } while (0)
-        if (nseg == 5) MOMA_WIDE_SCORES(5, 5, 640);
-        else if (nseg == 6) MOMA_WIDE_SCORES(6, 6, 768);
-        else if (nseg == 8) MOMA_WIDE_SCORES(8, 4, 1024);
-        else if (nseg == 10) MOMA_WIDE_SCORES(10, 5, 1280);
-        else if (nseg == 12) MOMA_WIDE_SCORES(12, 6, 1536);
+        if (nseg == 5) MOMA_WIDE_SCORES(5, 5, 640, 1);
+        else if (nseg == 6) MOMA_WIDE_SCORES(6, 6, 768, 1);
+        else if (nseg == 8) MOMA_WIDE_SCORES(8, 4, 1024, 1);
+        else if (nseg == 10) MOMA_WIDE_SCORES(10, 5, 1280, 1);
+        else if (nseg == 12) MOMA_WIDE_SCORES(12, 6, 1536, 1);
+        else if (nseg == 16) MOMA_WIDE_SCORES(8, 4, 2048, 2);
         else {
             if (ev_begin) (void)hipEventRecord(ev_begin, st);      // (slab passes: a pre-pack per slab sits between the passes)
             for (int col0 = 0; col0 < d; col0 += slab_width(col0)) {
@@ -1698,7 +1768,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         int cg = 1;
         const float* wide_ref = m_part;                        // reference of the O partials (the combine kernel's weights)
         if (dq) {
-            const bool wide_pv = nseg == 5 || nseg == 6 || nseg == 8 || nseg == 10 || nseg == 12;
+            const bool wide_pv = nseg == 5 || nseg == 6 || nseg == 8 || nseg == 10 || nseg == 12 || nseg == 16;
             if (wide_pv) {
                 // column ranges of 256 columns x 256 rows per workgroup; key chunks grouped (<= 8 per group) so that the grid is
                 // about one workgroup per CU
@@ -1710,9 +1780,9 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                 if (cg > 8) cg = 8;
                 const int ngroups = (p.nchunk + cg - 1) / cg;
                 wide_ref = r_part;
-#define MOMA_WIDE_PV(NS) hipExtLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), WIDE_PV2_LDS, st, (hipEvent_t) nullptr, ev_end, 0, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, (const uint4*)xs, r_part, o_part, (long)(slab_bytes / 16))
+#define MOMA_WIDE_PV(NS) hipExtLaunchKernelGGL((infonce_wide_pv2_kernel<NS>), dim3(8 * ((ngroups + 7) / 8) * nj), dim3(512), WIDE_PV2_LDS, st, (hipEvent_t) nullptr, ev_end, 0, qu, B, K, p.nchunk, p.tiles_per_chunk, cg, p.Bpad, (const uint4*)pscr, r_part, o_part, (long)(slab_bytes / 16))
                 if (nseg == 5) MOMA_WIDE_PV(5); else if (nseg == 6) MOMA_WIDE_PV(6); else if (nseg == 8) MOMA_WIDE_PV(8);
-                else if (nseg == 10) MOMA_WIDE_PV(10); else MOMA_WIDE_PV(12);
+                else if (nseg == 10) MOMA_WIDE_PV(10); else if (nseg == 12) MOMA_WIDE_PV(12); else MOMA_WIDE_PV(16);
 #undef MOMA_WIDE_PV
             } else {
                 int sl = 0;

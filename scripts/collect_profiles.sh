@@ -11,6 +11,7 @@ SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 prof() { d=$1; shift; timeout -k 10 400 rocprofv3 "$@" > $O/$d.log 2>&1 || echo "FAILED: $d"; echo "done $d"; }
 K2="python3 $R/scripts/bench_k2.py 256 512 65536 bf16 bf16"
 KW="python3 $R/scripts/bench_k2.py 256 1280 65536 bf16 bf16"
+KX="python3 $R/scripts/bench_k2.py 256 2048 65536 bf16 bf16"
 KF="python3 $R/scripts/bench_k2_f32.py"
 K1="python3 $R/scripts/bench_k1.py 256 512 4 bf16"
 STEP="python3 $R/bench.py --steps 6 --warmup 4 --no_cpu_baseline"
@@ -19,6 +20,7 @@ prof k2_fetch --pmc FETCH_SIZE -d $O/k2_fetch --output-format csv -- $K2 8
 prof k2_write --pmc WRITE_SIZE -d $O/k2_write --output-format csv -- $K2 8
 prof k2_sq --pmc $SQ -d $O/k2_sq --output-format csv -- $K2 8
 prof k2w --kernel-trace --stats -d $O/k2w --output-format csv -- $KW 20
+prof k2x --kernel-trace --stats -d $O/k2x --output-format csv -- $KX 20
 prof k2f --kernel-trace --stats -d $O/k2f --output-format csv -- $KF
 prof k2f_sq --pmc $SQ -d $O/k2f_sq --output-format csv -- $KF
 prof k2f_fetch --pmc FETCH_SIZE -d $O/k2f_fetch --output-format csv -- $KF
@@ -32,6 +34,7 @@ prof step_write --pmc WRITE_SIZE -d $O/step_write --output-format csv -- $STEP
 cd $R
 python scripts/summarise_profiles.py ${TAG}_k2 $O/k2
 python scripts/summarise_profiles.py ${TAG}_k2_d1280 $O/k2w
+python scripts/summarise_profiles.py ${TAG}_k2_d2048 $O/k2x
 python scripts/summarise_profiles.py ${TAG}_k2_f32 $O/k2f
 python scripts/summarise_profiles.py ${TAG}_k1 $O/k1
 python scripts/summarise_profiles.py ${TAG}_k4 $O/k4

@@ -145,7 +145,9 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
                                        # the one-pass wide kernels at their other widths (8 / 12 / 6 segments), ragged B and K,
                                        # several key chunks per group and a last 16-key tile that is partly past K
                                        (70, 1024, 3000, "bf16"), (257, 1536, 2500, "bf16"), (96, 768, 70001, "bf16"),
-                                       (5, 1280, 17, "bf16")])
+                                       (5, 1280, 17, "bf16"),
+                                       # d = 2048 (ResNet-50 `--head None`): scores in two register passes of Q (8 + 8 segments)
+                                       (256, 2048, 8192, "bf16"), (130, 2048, 3001, "bf16"), (3, 2048, 40, "bf16")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
@@ -177,7 +179,7 @@ def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
 
 
 @pytest.mark.parametrize("B,d,K", [(256, 512, 4096), (100, 384, 1000), (33, 256, 300), (128, 512, 65536), (70, 128, 2000), (50, 1280, 1500),
-                                   (160, 768, 3000), (256, 1280, 65536), (90, 1024, 20000)])
+                                   (160, 768, 3000), (256, 1280, 65536), (90, 1024, 20000), (256, 2048, 65536), (70, 2048, 5000)])
 def test_infonce_flash_queue_term(ops, B, d, K):
     """The sum_j p_bj * queue_j part of dq in isolation: k = 0 removes the positive-key term, and every query is
     aligned with a few queue rows so the softmax is peaked and the weighted key sum is O(1), not averaged away."""
@@ -203,7 +205,7 @@ def test_infonce_flash_queue_term(ops, B, d, K):
     assert err.max() < 2e-2, err.max()
 
 
-@pytest.mark.parametrize("d", [768, 1280])
+@pytest.mark.parametrize("d", [768, 1280, 2048])
 def test_infonce_wide_rows_large_logits_and_repeatable(ops, d):
     """Wide rows (d > 512): P = 2^(x - reference) with the reference = max over the chunk group of the chunk maxima of the score
     pass, so logits tens of nats apart (un-normalised attention outputs as q, reference MoMA/criterion_moco_att.py:153-167)
@@ -234,7 +236,7 @@ def test_infonce_wide_rows_large_logits_and_repeatable(ops, d):
 
 
 @pytest.mark.parametrize("grad", [True, False])
-@pytest.mark.parametrize("d", [256, 512, 768, 1280])
+@pytest.mark.parametrize("d", [256, 512, 768, 1280, 2048])
 @pytest.mark.parametrize("scale", [30.0, 25.0, 10.0, 6.0])
 def test_infonce_flash_overflow_repass(ops, scale, d, grad):
     """A key far down the chunk beats the first tile's max by tens to hundreds of log2 units.  Beyond the fixed
