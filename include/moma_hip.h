@@ -170,7 +170,8 @@ int moma_infonce_fused_multi(const moma_infonce_term_t* terms, int n_terms, int 
  *   Two families of entry points; moma_mha_saved_state() says which one a configuration takes:
  *
  *   MOMA_MHA_SAVE_LSE  ->  the FAST path (moma_mha_pack_weights / moma_mha_fwd_fast / moma_mha_bwd_fast): MOMA_PREC_BF16 with a
- *     head dim that is a multiple of 16 and <= 128 (every `--head mlp` configuration).  Flash-style: the forward keeps the
+ *     head dim that is a multiple of 16: up to 128 (every `--head mlp` configuration) at any N, wider heads up to 1024
+ *     (`--head None`: EfficientNet-B0 1280 / 4 = 320, ResNet-50 2048 / 4 = 512) at N <= 256.  Flash-style: the forward keeps the
  *     row log-sum-exp lse [H,N] (log2 units, scale included) and the backward recomputes P per tile, so no [H,N,N] array
  *     exists at any N (attn = 'all' runs over N = 2B + K tokens).  Everything a launch reads more than once is bf16:
  *       pack    caller-owned, moma_mha_pack_bytes(d) bytes: [Wqkv | Wproj | Wqkv^T | Wproj^T] as bf16, written by

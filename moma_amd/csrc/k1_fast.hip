@@ -1,5 +1,6 @@
 // K1 fast path: batch-token multi-head attention (MoMA/criterion_moco_att.py:153-167) under the bf16 policy for head dims that
-// are multiples of 16 and <= 128 -- every `--head mlp` configuration.  The problem is tiny (N = 256 tokens, d = 512: 0.67 GFLOP
+// are multiples of 16: up to 128 -- every `--head mlp` configuration -- at any N, wider heads (`--head None`: 1280 / 4 = 320) at
+// N <= 256.  The problem is tiny (N = 256 tokens, d = 512: 0.67 GFLOP
 // per module forward) and therefore bound by launches and by the bytes each compute unit can pull from L2 (60-70 GB/s per CU),
 // not by the matrix pipe.  The path is built around that:
 //   * every operand a kernel reads more than once per launch is stored as bf16 (weights: a pack refreshed when the optimizer
@@ -592,6 +593,131 @@ __global__ __launch_bounds__(NW * 64) void k1_core_fwd_kernel(CoreFwdArgs a) {
     }
 }
 
+
+// ---- wide heads (128 < head dim, e.g. `--head None` on EfficientNet-B0: d = 1280, 4 heads of 320), N <= 32 * NW -----------------
+// The products are separable over 128-column SEGMENTS of the head: S = sum_seg Q_seg K_seg^T, O_seg = P V_seg.  One key tile per
+// wave as in the ONE_TILE kernel; the segment images stream through the same two 8 KiB images per wave (and the one Q image of
+// the workgroup), so the LDS budget does not grow with the head dim: phase 1 accumulates the scores over the segments, the row
+// statistics follow, phase 2 forms one segment of O at a time (4 accumulator tiles) and sums it over the waves through LDS.
+__global__ __launch_bounds__(NW * 64) void k1_core_fwd_wide_kernel(CoreFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const CoreMod M = a.m[blockIdx.z];
+    const int N = a.N, d = a.d, hd = d / a.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h2 = lane >> 5;
+    const int head = blockIdx.y, q0 = blockIdx.x * 32;
+    const long ld = 3L * d;
+    const int nseg = (hd + 127) >> 7;
+    const bf16_raw* qb = M.qkv + head * hd;
+    const bf16_raw* kb = M.qkv + d + head * hd;
+    const bf16_raw* vb = M.qkv + 2 * d + head * hd;
+    char* imgQ = smem;
+    char* imgK = smem + 8192 + wave * 16384;
+    char* imgV = imgK + 8192;
+    float* s_ml = reinterpret_cast<float*>(smem + 8192 + NW * 16384);
+    const unsigned boff = tr_lane_offset(lane);
+
+    // ---- phase 1: the wave's score tile, accumulated over the segments (V's first segment rides along)
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = 0.f;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, kse = w >> 4;
+        if (sg) __syncthreads();                                 // every wave is done with the previous Q image
+        dma_piece(qb, ld, q0, N, c0, nch, imgQ, wave, lane);
+        dma_tile32(kb, ld, wave * KT, N, c0, nch, imgK, lane);
+        if (sg == 0) dma_tile32(vb, ld, wave * KT, N, 0, nch, imgV, lane);
+        wait_dma();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < kse) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(imgK, n, h2, ks), row_frag(imgQ, n, h2, ks), x, 0, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    if ((wave + 1) * KT > N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (wave * KT + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) x[r] = NEG_BIG;
+    }
+    // ---- the row log-sum-exp over the waves' tiles
+    float lse2;
+    {
+        float tmax = x[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
+        tmax = fmaxf(tmax, other_half(tmax));
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(x[r] - tmax);
+        ps += other_half(ps);
+        if (h2 == 0) {
+            s_ml[(wave * 32 + n) * 2 + 0] = tmax;
+            s_ml[(wave * 32 + n) * 2 + 1] = ps;
+        }
+        __syncthreads();
+        float mm = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, s_ml[(w * 32 + n) * 2]);
+        float ll = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ll += s_ml[(w * 32 + n) * 2 + 1] * __builtin_amdgcn_exp2f(s_ml[(w * 32 + n) * 2] - mm);
+        lse2 = mm + __builtin_amdgcn_logf(ll);                   // v_log_f32 = log2
+    }
+    if (M.lse != nullptr && wave == 0 && h2 == 0 && q0 + n < N) M.lse[(long)head * N + q0 + n] = lse2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
+    const bf16x8 pa0 = tile_as_a(x, 0), pa1 = tile_as_a(x, 1);
+
+    // ---- phase 2: O_seg = sum over the waves of P . V_seg
+    float* s_o = reinterpret_cast<float*>(smem + 8192);
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, nct = (w + 31) >> 5;
+        if (sg) {
+            dma_tile32(vb, ld, wave * KT, N, c0, nch, imgV, lane);
+            wait_dma();
+        }
+        f32x16 O[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+        const unsigned vl = lds_addr(imgV);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 vf[4];
+            tr_frags4(vl, boff, s, vf);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < nct) O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? pa0 : pa1, vf[c], O[c], 0, 0, 0);
+        }
+        // the wave's slice (its own two images: consumed) takes its partial; O[c][r] = query (r&3)+8(r>>2)+4h2, column 32c+n
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_o[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2) * 128 + 32 * c + n] = O[c][r];
+        __syncthreads();
+        {
+            const int row = tid >> 4, col = (tid & 15) * 8;      // 512 threads = 32 rows x 16 chunks of 8 columns
+            float4 s0 = *reinterpret_cast<const float4*>(&s_o[row * 128 + col]);
+            float4 s1 = *reinterpret_cast<const float4*>(&s_o[row * 128 + col + 4]);
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) {
+                const float4 u0 = *reinterpret_cast<const float4*>(&s_o[(ww * 32 + row) * 128 + col]);
+                const float4 u1 = *reinterpret_cast<const float4*>(&s_o[(ww * 32 + row) * 128 + col + 4]);
+                s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+                s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+            }
+            if (q0 + row < N && col < w) {
+                uint4 o;
+                o.x = pack_bf16(s0.x, s0.y); o.y = pack_bf16(s0.z, s0.w); o.z = pack_bf16(s1.x, s1.y); o.w = pack_bf16(s1.z, s1.w);
+                *reinterpret_cast<uint4*>(M.out + (long)(q0 + row) * d + head * hd + c0 + col) = o;
+            }
+        }
+        __syncthreads();                                         // the slices are free again
+    }
+}
+
 // =====================================================================================================================
 // Per-head core, backward (flash-style: P recomputed per tile from Q, K and the forward's row log-sum-exp).
 //   S = Qs K^T (log2 units) ; P = 2^(S - lse2) ; dP = dA_h V_h^T ; D = rowsum(dA o a) ; dS = P o (dP - D) * scale
@@ -785,6 +911,155 @@ __global__ __launch_bounds__(NW * 64) void k1_core_bwd_kernel(CoreBwdArgs a) {
     else k1_core_bwd_role<true, FULL>(smem, a);
 }
 
+
+// ---- wide heads, backward: the same two roles with the head's columns in 128-column segments and one reduction tile per wave
+// (N <= 32 * NW).  Phase 1: X and S accumulate over the segments (the block images and the wave's tile images are re-filled per
+// segment); P and dS follow once; phase 2 forms one segment of dQ (or dK and dV) at a time and sums it over the waves.
+template <bool ROLE_KV>
+__device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdArgs& a) {
+    const int N = a.N, d = a.d, hd = d / a.H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h2 = lane >> 5;
+    const int head = blockIdx.y, b0 = blockIdx.x * 32;
+    const long ld = 3L * d;
+    const int nseg = (hd + 127) >> 7, npart = hd >> 4;
+    const bf16_raw* qb = a.qkv + head * hd;
+    const bf16_raw* kb = a.qkv + d + head * hd;
+    const bf16_raw* vb = a.qkv + 2 * d + head * hd;
+    const bf16_raw* dab = a.dA + head * hd;
+    const float* Lh = a.lse + (long)head * N;
+    const float* Dp = a.dpart + (long)head * npart * N;
+    const float scale = 1.0f / sqrtf((float)hd);
+    char* imgR = smem;                      // ROLE_Q: dA_blk ; ROLE_KV: V_blk   (B operand of X)
+    char* imgS = smem + 8192;               // ROLE_Q: Qs_blk ; ROLE_KV: K_blk   (B operand of S)
+    char* img1 = smem + 16384 + wave * 16384;   // ROLE_Q: V_t ; ROLE_KV: dA_t
+    char* img2 = img1 + 8192;                   // ROLE_Q: K_t ; ROLE_KV: Qs_t
+    float* sLD = reinterpret_cast<float*>(smem + 16384 + NW * 16384) + wave * 64;    // [32] lse | [32] D of the tile rows
+    const unsigned boff = tr_lane_offset(lane);
+    const int t0 = wave * KT;
+    const bool lane_ok = b0 + n < N;
+    float Ln = 0.f, Dn = 0.f;
+    if (!ROLE_KV && lane_ok) {
+        Ln = Lh[b0 + n];
+        for (int i = 0; i < npart; ++i) Dn += Dp[(long)i * N + b0 + n];
+    }
+    if (ROLE_KV && h2 == 0) {
+        const int q = min(t0 + n, N - 1);
+        float dsum = 0.f;
+        for (int i = 0; i < npart; ++i) dsum += Dp[(long)i * N + q];
+        sLD[n] = Lh[q];
+        sLD[32 + n] = dsum;
+    }
+    f32x16 x, sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = 0.f; sc[r] = 0.f; }
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, kse = w >> 4;
+        if (sg) __syncthreads();                                 // every wave is done with the previous block images
+        if constexpr (!ROLE_KV) {
+            dma_piece(dab, d, b0, N, c0, nch, imgR, wave, lane);
+            dma_piece(qb, ld, b0, N, c0, nch, imgS, wave, lane);
+            dma_tile32(vb, ld, t0, N, c0, nch, img1, lane);
+            dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
+        } else {
+            dma_piece(vb, ld, b0, N, c0, nch, imgR, wave, lane);
+            dma_piece(kb, ld, b0, N, c0, nch, imgS, wave, lane);
+            dma_tile32(dab, d, t0, N, c0, nch, img1, lane);
+            dma_tile32(qb, ld, t0, N, c0, nch, img2, lane);
+        }
+        wait_dma();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < kse) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img1, n, h2, ks), row_frag(imgR, n, h2, ks), x, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (ks < kse) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img2, n, h2, ks), row_frag(imgS, n, h2, ks), sc, 0, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    f32x16 p, ds;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 l4, d4;
+        if constexpr (ROLE_KV) {
+            l4 = *reinterpret_cast<const float4*>(&sLD[8 * g + 4 * h2]);
+            d4 = *reinterpret_cast<const float4*>(&sLD[32 + 8 * g + 4 * h2]);
+        } else {
+            l4 = make_float4(Ln, Ln, Ln, Ln);
+            d4 = make_float4(Dn, Dn, Dn, Dn);
+        }
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            const int tr = t0 + 8 * g + 4 * h2 + i;
+            const float pv = __builtin_amdgcn_exp2f(sc[r] - lv[i]);
+            p[r] = (tr < N && lane_ok) ? pv : 0.f;
+            ds[r] = p[r] * (x[r] - dv[i]) * (ROLE_KV ? 0.6931471805599453f : scale);
+        }
+    }
+    const bf16x8 dsa0 = tile_as_a(ds, 0), dsa1 = tile_as_a(ds, 1);
+    const bf16x8 pa0 = tile_as_a(p, 0), pa1 = tile_as_a(p, 1);
+    float* s_o = reinterpret_cast<float*>(smem + 16384);
+    __syncthreads();
+    for (int sg = nseg - 1; sg >= 0; --sg) {                     // (the last segment's tile images are still in place: it goes first)
+        const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, nct = (w + 31) >> 5;
+        if (sg != nseg - 1) {
+            if constexpr (!ROLE_KV) {
+                dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
+            } else {
+                dma_tile32(dab, d, t0, N, c0, nch, img1, lane);
+                dma_tile32(qb, ld, t0, N, c0, nch, img2, lane);
+            }
+            wait_dma();
+        }
+        f32x16 acc0[4], acc1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
+        if constexpr (!ROLE_KV) {
+            const unsigned kl = lds_addr(img2);                 // dQ_seg = dS . K_t,seg
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 f[4];
+                tr_frags4(kl, boff, s, f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nct) acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? dsa0 : dsa1, f[c], acc0[c], 0, 0, 0);
+            }
+            reduce_store16(s_o, acc0, a.dqkv + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
+        } else {
+            const unsigned al = lds_addr(img1), ql = lds_addr(img2);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                        // dV_seg = P' . dA_t,seg
+                bf16x8 f[4];
+                tr_frags4(al, boff, s, f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nct) acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? pa0 : pa1, f[c], acc1[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                        // dK_seg = dS' . Qs_t,seg  (ln 2 folded into dS')
+                bf16x8 f[4];
+                tr_frags4(ql, boff, s, f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nct) acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? dsa0 : dsa1, f[c], acc0[c], 0, 0, 0);
+            }
+            reduce_store16(s_o, acc0, a.dqkv + d + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
+            reduce_store16(s_o, acc1, a.dqkv + 2 * d + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NW * 64) void k1_core_bwd_wide_kernel(CoreBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.z == 0) k1_core_bwd_wide_role<false>(smem, a);
+    else k1_core_bwd_wide_role<true>(smem, a);
+}
+
 void core_attrs_once() {
     static std::once_flag once;                           // (one device per process: include/moma_hip.h)
     std::call_once(once, [] {
@@ -794,6 +1069,8 @@ void core_attrs_once() {
         (void)hipFuncSetAttribute((const void*)k1_core_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
         (void)hipFuncSetAttribute((const void*)k1_core_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
         (void)hipFuncSetAttribute((const void*)k1_core_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
         (void)hipFuncSetAttribute((const void*)k1_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     });
 }
@@ -841,7 +1118,8 @@ K1Job ks_job(const void* A, int a_f32, long lda, const void* B, int b_f32, long 
 bool mha_fast_supported(int N, int d, int H, int prec) {
     if (prec != MOMA_PREC_BF16 || H <= 0 || d % H || N < 1) return false;
     const int hd = d / H;
-    return hd % 16 == 0 && hd <= 128;
+    // head dims up to 128: any N.  Wider heads (segments of 128 columns, k1_core_*_wide_kernel): one key tile per wave
+    return hd % 16 == 0 && (hd <= 128 || (hd <= 1024 && N <= KT * NW));
 }
 
 hipError_t launch_mha_pack(const float* w_qkv, const float* w_proj, void* pack, int d, int with_t, hipStream_t st) {
@@ -872,7 +1150,8 @@ hipError_t launch_mha_fwd_fast(const moma_mha_module_t* mods, int n_modules, int
     for (int i = 0; i < n_modules; ++i) ca.m[i] = CoreMod{(const bf16_raw*)mods[i].qkv16, (bf16_raw*)mods[i].attn16, mods[i].lse};
     const dim3 grid((N + 31) / 32, H, n_modules), block(NW * 64);
     const bool one = N <= KT * NW, full = hd == 128;                                                       // (:159-163)
-    if (one && full) hipLaunchKernelGGL((k1_core_fwd_kernel<true, true>), grid, block, CORE_LDS, st, ca);
+    if (hd > 128) hipLaunchKernelGGL(k1_core_fwd_wide_kernel, grid, block, CORE_LDS, st, ca);
+    else if (one && full) hipLaunchKernelGGL((k1_core_fwd_kernel<true, true>), grid, block, CORE_LDS, st, ca);
     else if (one) hipLaunchKernelGGL((k1_core_fwd_kernel<true, false>), grid, block, CORE_LDS, st, ca);
     else if (full) hipLaunchKernelGGL((k1_core_fwd_kernel<false, true>), grid, block, CORE_LDS, st, ca);
     else hipLaunchKernelGGL((k1_core_fwd_kernel<false, false>), grid, block, CORE_LDS, st, ca);
@@ -918,7 +1197,8 @@ hipError_t launch_mha_bwd_fast(const void* pack, const void* x, int x_dtype, con
     if (e != hipSuccess) return e;
     // launch 2: the per-head core
     CoreBwdArgs ca{(const bf16_raw*)qkv16, dA16, lse, dpart, dqkv16, N, d, H};
-    if (d / H == 128) hipLaunchKernelGGL(k1_core_bwd_kernel<true>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
+    if (d / H > 128) hipLaunchKernelGGL(k1_core_bwd_wide_kernel, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
+    else if (d / H == 128) hipLaunchKernelGGL(k1_core_bwd_kernel<true>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
     else hipLaunchKernelGGL(k1_core_bwd_kernel<false>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

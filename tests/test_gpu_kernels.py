@@ -375,7 +375,7 @@ def test_mha_golden(ops, golden_dir, prec, rtol, atol):
                                        err_msg=f"case {ci} {nm}")
 
 
-@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (64, 384, 8), (100, 1280, 4), (300, 256, 4)])
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (64, 384, 8), (100, 1280, 4), (300, 256, 4), (256, 1280, 4), (300, 1280, 4)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_mha_vs_oracle(ops, N, d, H, prec):
     rng = np.random.default_rng(N + d)
@@ -398,7 +398,9 @@ def test_mha_vs_oracle(ops, N, d, H, prec):
         assert err < tol, (nm, err)
 
 
-@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (1, 64, 4), (33, 128, 8), (129, 256, 2), (1000, 512, 4), (77, 192, 4)])
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (1, 64, 4), (33, 128, 8), (129, 256, 2), (1000, 512, 4), (77, 192, 4),
+                                   # wide heads (`--head None`: 1280 / 4 = 320, 2048 / 4 = 512; 160 = one full + one partial segment)
+                                   (256, 1280, 4), (200, 2048, 4), (37, 320, 2), (256, 1024, 1)])
 def test_mha_fused_core_no_grad(ops, N, d, H):
     """bf16 policy, head dim multiple of 16 and <= 128: the per-head core is one fused launch that keeps the row
     log-sum-exp for the backward and never materialises the probabilities (no [H,N,N] at the ABI).  The no-grad call and
@@ -427,7 +429,8 @@ def test_mha_fused_core_no_grad(ops, N, d, H):
     assert err < 3e-2, err
 
 
-@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (33, 128, 8), (129, 256, 2), (300, 512, 4), (77, 192, 4), (64, 64, 4)])
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (33, 128, 8), (129, 256, 2), (300, 512, 4), (77, 192, 4), (64, 64, 4),
+                                   (256, 1280, 4), (130, 2048, 4), (37, 320, 2), (250, 288, 1)])
 def test_mha_fused_bwd_peaked(ops, N, d, H):
     """Fused per-head backward core (bf16 policy): peaked softmax rows (large q / k weights) so that a wrong pairing of
     tile rows between the two MFMA products of dQ / dK / dV cannot hide behind near-uniform attention; ragged N, head
@@ -452,7 +455,7 @@ def test_mha_fused_bwd_peaked(ops, N, d, H):
         assert err < 4e-2, (nm, err)
 
 
-@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (100, 192, 4), (300, 128, 8)])
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (100, 192, 4), (300, 128, 8), (256, 1280, 4)])
 def test_mha_group_equals_single_calls(ops, N, d, H):
     """Attention.forward_group (the loop's atts_k + atts_queue, helper/loops_moma.py:327-329, as ONE group of three launches)
     returns bit for bit what the modules return one by one; a weight change is picked up by the bf16 pack."""
@@ -539,11 +542,11 @@ def test_mha_fast_path_takes_bf16_input_and_follows_raw_pointer_weight_updates(o
 
 
 # ------------------------------------------------------------------------------------------------ ABI
-def test_mha_bitwise_repeatable_gradients(ops):
+@pytest.mark.parametrize("N,d,H", [(256, 512, 4), (256, 1280, 4)])
+def test_mha_bitwise_repeatable_gradients(ops, N, d, H):
     """Two forward + backward runs on the same inputs give bit-identical outputs and weight gradients in both policies
     (round 1 used split-K fp32 atomics in the linears: d_wqkv changed in the last bits from run to run)."""
     rng = np.random.default_rng(5)
-    N, d, H = 256, 512, 4
     x = O.l2_normalize(rng.standard_normal((N, d)).astype(np.float32))
     bound = 1.0 / np.sqrt(d)
     ws = [rng.uniform(-bound, bound, shp).astype(np.float32) for shp in ((3 * d, d), (3 * d,), (d, d), (d,))]
