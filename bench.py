@@ -312,6 +312,7 @@ def main():
     torch.manual_seed(12345)                         # identical initial weights on every rank
     model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
     trainer = ContrastTrainer(opt)
+    trainer.grad_sync_single_rank = distributed and world == 1      # (the rehearsal runs the hook-launched all-reduce on its one rank)
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if distributed:
@@ -487,6 +488,7 @@ def main():
         if distributed:      # what the N>1 line was measured with (the driver checks it against its own launch)
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                            "replica_checksum_spread": {"student": spread[0], "criterion": spread[1], "ema_teacher": spread[2]},
+                           "criterion_allreduce_launches": int(getattr(trainer, "grad_sync_launches", 0)),
                            "overlap_teacher": bool(opt.overlap_teacher), "graph_teacher": bool(getattr(opt, "graph_teacher", True)),
                            "collective": "DDP bucketed gradient all-reduce (student) + one flat async all-reduce of the "
                                          "trainable criterion modules per step; per-rank queue, no data-path gather"}

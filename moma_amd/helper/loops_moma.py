@@ -57,7 +57,8 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
     ema_ok = None
     mocoatt = getattr(opt, "mem", "MoCo") == "MoCoAtt"
     attn_in_shuffle = opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix") and not mocoatt
-    if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
+    sync_criterion = opt.distill == "moma" and (getattr(opt, "world_size", 1) > 1 or getattr(trainer, "grad_sync_single_rank", False))
+    if sync_criterion:
         # one flat all-reduce per step for the trainable criterion modules, launched from autograd hooks (overlaps backward)
         trainer.attach_grad_sync([p for p in criterion_kd.parameters() if p.requires_grad])
     # the teacher's two no-grad forwards per step are replayed from a HIP graph after a few eager calls
@@ -203,7 +204,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             scaler.scale(loss).backward()
         else:
             loss.backward()
-        if opt.distill == "moma" and getattr(opt, "world_size", 1) > 1:
+        if sync_criterion:
             trainer.finish_grad_sync()                  # atts_q / embed_s are not under DDP (fixes Q7)
         if scaler is not None:
             scaler.step(optimizer)

@@ -171,8 +171,11 @@ class ContrastTrainer(BaseTrainer):
     # step, launched from autograd hooks the moment the last of them is accumulated -- these modules sit at the top of the
     # graph, so the collective overlaps the whole backbone backward -- and waited for right before optimizer.step().
     def attach_grad_sync(self, params):
-        """Register the hooks once per parameter list (no-op without a process group or at world size 1)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        """Register the hooks once per parameter list (no-op without a process group or at world size 1 -- unless
+        `self.grad_sync_single_rank` is set: the one-rank rehearsal of the collective path, bench.py MOMA_BENCH_FORCE_DIST)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() == 1 and not getattr(self, "grad_sync_single_rank", False):
             return
         params = [p for p in params if p.requires_grad]
         if getattr(self, "_gs_params", None) is not None and [id(p) for p in self._gs_params] == [id(p) for p in params]:
@@ -197,6 +200,7 @@ class ContrastTrainer(BaseTrainer):
         self._gs_grads = grads
         self._gs_flat = torch.cat([g.reshape(-1) for g in grads])
         self._gs_work = dist.all_reduce(self._gs_flat, async_op=True)
+        self.grad_sync_launches = getattr(self, "grad_sync_launches", 0) + 1
 
     def finish_grad_sync(self):
         """Wait for the step's criterion all-reduce (launching it now if the hooks did not see every gradient, e.g. a

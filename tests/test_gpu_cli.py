@@ -157,6 +157,7 @@ def test_bench_two_ranks_on_one_gpu_replicas_stay_in_sync(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
     d = out["dist"]
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["overlap_teacher"] and d["graph_teacher"]
+    assert d["criterion_allreduce_launches"] == 5 + 6
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}, d
 
 
@@ -180,5 +181,6 @@ def test_bench_one_rank_on_rccl(tmp_path):
     d = out["dist"]
     assert d["world_size"] == 1 and d["backend"] == "nccl" and d["overlap_teacher"] and d["graph_teacher"]
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}
+    assert d["criterion_allreduce_launches"] == 5 + 8           # one flat all-reduce per warm-up and timed step
     assert out["ms_per_step_max"] < 3.0 * out["ms_per_step_median"], out
     assert "Loss nan" not in r.stderr
