@@ -316,7 +316,8 @@ def main():
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if distributed:
-        ddp_s = nn.parallel.DistributedDataParallel(model_s, device_ids=[local], gradient_as_bucket_view=True)
+        from moma_amd.learning.ddp import wrap_student
+        ddp_s = wrap_student(model_s, device_ids=[local])
         opt.gpu = local
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()

@@ -271,8 +271,8 @@ def main_worker(gpu, ngpus_per_node, opt):
     if contrast is not None:
         trainer.broadcast_memory(contrast)                       # optional step: synchronize memory (:336)
     if opt.multiprocessing_distributed:
-        ddp_s = torch.nn.parallel.DistributedDataParallel(model_s, device_ids=[opt.gpu] if device.type == "cuda" else None,
-                                                          gradient_as_bucket_view=True)
+        from .learning.ddp import wrap_student
+        ddp_s = wrap_student(model_s, device_ids=[opt.gpu] if device.type == "cuda" else None)
         module_list = [ddp_s] + [m for m in list(module_list)[1:]]
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")

@@ -98,7 +98,8 @@ def _worker(rank, world, port, shuffle_mode, out):
     trainer.broadcast_memory(contrast)
     trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
     optimizer = torch.optim.SGD(trainable.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
-    ddp = nn.parallel.DistributedDataParallel(ms)
+    from moma_amd.learning.ddp import wrap_student
+    ddp = wrap_student(ms)                                  # the product's wrap: stock reducer + flat buffer broadcast
     mods = [ddp, mt]
     crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
     g = torch.Generator().manual_seed(100 + rank)          # different data shard per rank
@@ -200,3 +201,53 @@ def test_criterion_grad_sync_survives_a_changing_gradient_set(tmp_path):
     for r in range(2):
         res = torch.load(f"{out}.rank{r}")
         assert res["ok"] and res["expect"] == 6
+
+
+def _wrap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    from moma_amd.learning.ddp import wrap_student
+
+    def net():
+        torch.manual_seed(3)
+        return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1),
+                             nn.BatchNorm2d(8), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5))
+    a, b = net(), net()
+    stock = nn.parallel.DistributedDataParallel(a)                       # the reference's wrap (stock defaults)
+    ours = wrap_student(b)
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.1, momentum=0.9), torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(50 + rank)                         # a different shard per rank
+    for _ in range(3):
+        x, y = torch.randn(6, 3, 8, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
+        for m, o in ((stock, oa), (ours, ob)):
+            o.zero_grad(set_to_none=True)
+            nn.functional.cross_entropy(m(x), y).backward()
+            o.step()
+    stock.eval(), ours.eval()
+    with torch.no_grad():                                                # one more forward (eval: no local update behind the
+        stock(x), ours(x)                                                # broadcast): both wraps leave rank 0's buffers everywhere
+    res = dict(pa=[p.detach().clone() for p in a.parameters()], pb=[p.detach().clone() for p in b.parameters()],
+               ba=[t.clone() for t in a.buffers()], bb=[t.clone() for t in b.buffers()])
+    torch.save(res, os.path.join(out, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_student_wrap_equals_stock_ddp(tmp_path):
+    """learning/ddp.py:wrap_student (stock reducer + one flat buffer broadcast per dtype) against stock
+    DistributedDataParallel -- the reference's wrap, train_student_moma.py:345-349 -- on two gloo ranks with different shards:
+    parameters after three SGD steps and BatchNorm buffers (incl. the int64 batch counters) are the same, on both ranks."""
+    world, port = 2, _free_port()
+    mp.spawn(_wrap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    for r in (r0, r1):
+        for pa, pb in zip(r["pa"], r["pb"]):
+            assert torch.allclose(pa, pb, rtol=0, atol=1e-7)
+        for ba, bb in zip(r["ba"], r["bb"]):
+            assert torch.equal(ba, bb)
+    for b0, b1 in zip(r0["bb"], r1["bb"]):
+        assert torch.equal(b0, b1)                                       # rank 0's statistics everywhere
+    for p0, p1 in zip(r0["pb"], r1["pb"]):
+        assert torch.equal(p0, p1)
