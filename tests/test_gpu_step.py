@@ -386,11 +386,12 @@ def test_loop_cross_attention_paths_match_step_oracle(mem, attn):
     np.testing.assert_allclose(contrast.memory.cpu().numpy(), ocontrast.memory.numpy(), rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize("d,K", [(768, 8192), (1280, 16384)])
+@pytest.mark.parametrize("d,K", [(768, 8192), (1280, 16384), (2048, 8192)])
 def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
-    """Wide feature dims (the regime of the reference CLI's default `--head None`: EfficientNet-B0 -> d = 1280) at LOOP level under
-    the bf16 policy: the two-pass wide-row K2 (infonce_wide_scores_kernel + infonce_wide_pv2_kernel, bf16 queue), the staged K1
-    path with its batched K-split products (head dim 192 / 320 > 128), K3, K4; teacher side on the second stream.  3 steps of
+    """Wide feature dims (the regime of the reference CLI's default `--head None`: EfficientNet-B0 -> d = 1280, ResNet-50 -> 2048) at
+    LOOP level under the bf16 policy: the two-pass wide-row K2 (infonce_wide_scores_kernel -- at d = 2048 in two register passes of
+    Q -- + infonce_wide_pv2_kernel, bf16 queue), K1 on the wide-head fast path (head dim 192 / 320 / 512 > 128: segment-streamed
+    cores), K3, K4; teacher side on the second stream.  3 steps of
     train_distill_moma against the CPU step oracle (fp32; its pieces are pinned to the reference by G1-G5).  Tolerances as in
     the big-queue test: first step 1e-3 relative (the kernels' own error), later steps 5e-3 (bf16 gradient rounding through SGD)."""
     if not torch.cuda.is_available():
