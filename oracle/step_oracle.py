@@ -42,7 +42,10 @@ def _head(kind, in_dim, feat_dim):
     flat, norm = nn.Flatten(1), _Normalize()
     if kind == "mlp":
         return nn.Sequential(flat, nn.Linear(in_dim, in_dim), nn.ReLU(inplace=True), nn.Linear(in_dim, feat_dim), norm)
-    if kind == "linear":
+    if kind == "mlp_byol":                                                     # :269-285
+        return nn.Sequential(flat, nn.Linear(in_dim, in_dim), nn.BatchNorm1d(in_dim), nn.ReLU(inplace=True),
+                             nn.Linear(in_dim, feat_dim), norm)
+    if kind == "linear":                                                       # :286-297
         return nn.Sequential(flat, nn.Linear(in_dim, feat_dim), norm)
     return nn.Sequential(flat, norm)
 

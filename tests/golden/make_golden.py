@@ -19,6 +19,7 @@ What is captured:
   G9 world size 2 learning/contrast_trainer.py:90-187 + MoMA/mem_moco.py:77-100   the reference's Shuffle-BN collectives (image
                  all_gather, id broadcast, key all_gather) and the global enqueue on TWO gloo ranks: per-rank k / all_k / queue
   G5c step trace helper/loops_moma.py:221-373         the loop at the BENCHMARK's batch: B = 256, K = 65536, d = 512
+  G10 step trace helper/loops_moma.py:221-373         G5's loop with the CMO heads 'linear' and 'mlp_byol' (MoMA/criterion_moco_att.py:269-297)
 
 Only arrays (inputs / expected outputs) are written; no reference source text is stored.
 Shims needed to import the reference on a CPU-only box: a stub
@@ -224,6 +225,19 @@ def g7_mocoatt():
 def g5_step_trace():
     """10 steps of the reference loop, resnet8 student/teacher (same arch so the zip-EMA is defined,
     SURVEY Q4), B=8, 32x32, n_cls=100, K=64, head in {None, mlp}, -c 1 -d 1 -b 1, attn=self."""
+    _step_trace([("None", 64), ("mlp", 32)], "g5_step_trace.npz", 0)
+
+
+def g10_step_trace_heads():
+    """G5's loop with the remaining CMO heads (MoMA/criterion_moco_att.py:269-297): 'linear' (a CLI choice) and 'mlp_byol'
+    (Linear - BatchNorm1d - ReLU - Linear).  As the reference's train_student_moma.py:339-343 only registers embed_s with the
+    optimizer (and puts embed_t in eval mode) for head == 'mlp', these heads stay at their initial weights, both BatchNorm1d
+    layers stay in training mode (batch statistics, running statistics updated on every forward), and the loop's EMA leaves
+    embed_t alone (helper/loops_moma.py:310-312): the fixture also records the heads' final state."""
+    _step_trace([("linear", 32), ("mlp_byol", 32)], "g10_step_trace_heads.npz", 100)
+
+
+def _step_trace(cases, fname, seed_off):
     import argparse
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -240,7 +254,8 @@ def g5_step_trace():
         dist.init_process_group("gloo", rank=0, world_size=1)
 
     out = {}
-    for ci, (head, feat_dim) in enumerate([("None", 64), ("mlp", 32)]):
+    for ci0, (head, feat_dim) in enumerate(cases):
+        ci = ci0 + seed_off                                 # (seeds; the keys are numbered from 0 in every file)
         opt = argparse.Namespace(
             distill="moma", head=head, feat_dim=feat_dim, attn="self", mem="MoCo", nce_k=64, nce_t=0.15,
             alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=None, multiprocessing_distributed=True,
@@ -263,7 +278,7 @@ def g5_step_trace():
         if head == "mlp":
             trainable.append(criterion_kd.embed_s)
         optimizer = torch.optim.SGD(trainable.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
-        p = f"c{ci}_"
+        p = f"c{ci0}_"
         for name, t in model_s.state_dict().items():
             out[p + "s." + name] = t.numpy().copy()
         for name, t in model_t.state_dict().items():
@@ -340,8 +355,12 @@ def g5_step_trace():
         out[p + "kd_final.atts_q.proj.weight"] = criterion_kd.atts_q.proj.weight.detach().numpy().copy()
         out[p + "kd_final.atts_k.proj.weight"] = criterion_kd.atts_k.proj.weight.detach().numpy().copy()
         out[p + "head"] = np.array(head)
-    out["n_cases"] = np.array(2)
-    np.savez_compressed(os.path.join(OUT, "g5_step_trace.npz"), **out)
+        if seed_off:                                        # G10: the heads' final state (weights untouched, BN statistics moved)
+            for name, t in criterion_kd.state_dict().items():
+                if name.startswith("embed_"):
+                    out[p + "kd_final." + name] = t.numpy().copy()
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def g8_shuffle_bn_attn():
@@ -721,7 +740,7 @@ def g5c_step_trace_b256():
 if __name__ == "__main__":
     _shims()
     torch.set_num_threads(1)          # deterministic reduction order for the captured vectors
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b", "g8", "g9", "g5c"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g5b", "g8", "g9", "g5c", "g10"]
     if "g1" in which: g1_attention()
     if "g2" in which: g2_queue()
     if "g3" in which: g3_ema()
@@ -733,6 +752,7 @@ if __name__ == "__main__":
     if "g8" in which: g8_shuffle_bn_attn()
     if "g9" in which: g9_gather_w2()
     if "g5c" in which: g5c_step_trace_b256()
+    if "g10" in which: g10_step_trace_heads()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

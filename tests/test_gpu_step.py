@@ -18,12 +18,14 @@ def _sd(g, prefix):
     return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
 
 
-@pytest.mark.parametrize("ci", [0, 1])
+@pytest.mark.parametrize("fixture,ci", [("g5_step_trace.npz", 0), ("g5_step_trace.npz", 1),
+                                        ("g10_step_trace_heads.npz", 0), ("g10_step_trace_heads.npz", 1)])
 @pytest.mark.parametrize("fused,overlap", [(True, False), (False, False), (True, True)])
-def test_loop_matches_reference_trace(golden_dir, ci, fused, overlap):
-    """10 steps of train_distill_moma against the trace captured from the reference (G5): losses, queue pointer, final
-    queue / weights.  overlap = the teacher / key side of every step on a second HIP stream (and, from the 4th call on,
-    the teacher forwards replayed from HIP graphs): scheduling only, the numbers must not move."""
+def test_loop_matches_reference_trace(golden_dir, fixture, ci, fused, overlap):
+    """10 steps of train_distill_moma against the trace captured from the reference (G5: heads None / mlp; G10: heads linear /
+    mlp_byol, which the reference leaves untrained and -- mlp_byol -- with both BatchNorm1d layers in training mode): losses,
+    queue pointer, final queue / weights.  overlap = the teacher / key side of every step on a second HIP stream (and, from the
+    4th call on, the teacher forwards replayed from HIP graphs): scheduling only, the numbers must not move."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from moma_amd.backbones.resnet_cifar import resnet8
@@ -34,7 +36,7 @@ def test_loop_matches_reference_trace(golden_dir, ci, fused, overlap):
     from moma_amd.distiller_zoo import DistillKL
 
     torch.backends.cudnn.benchmark = False
-    g = np.load(os.path.join(golden_dir, "g5_step_trace.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     p = f"c{ci}_"
     head = str(g[p + "head"])
     feat_dim = 64 if head == "None" else 32
@@ -78,6 +80,15 @@ def test_loop_matches_reference_trace(golden_dir, ci, fused, overlap):
     np.testing.assert_allclose(mt.fc.weight.detach().cpu().numpy(), g[p + "t_final.fc.weight"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(kd.atts_q.proj.weight.detach().cpu().numpy(), g[p + "kd_final.atts_q.proj.weight"],
                                rtol=0, atol=2e-3)
+    if fixture.startswith("g10"):
+        final = _sd(g, p + "kd_final.")
+        for name, t in kd.state_dict().items():
+            if not name.startswith("embed_"):
+                continue
+            if "running" in name or "num_batches" in name:                   # BatchNorm1d statistics moved like the reference's
+                np.testing.assert_allclose(t.float().cpu().numpy(), final[name].float().numpy(), rtol=0, atol=2e-3)
+            else:                                                            # weights: never registered with the optimizer
+                assert np.array_equal(t.cpu().numpy(), final[name].numpy()), name
 
 
 @pytest.mark.parametrize("ci", [0, 1, 2])

@@ -16,10 +16,12 @@ def _sd(g, prefix):
     return {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
 
 
-@pytest.mark.parametrize("ci", [0, 1])
-def test_step_trace_matches_reference(golden_dir, ci):
+@pytest.mark.parametrize("fixture,ci", [("g5_step_trace.npz", 0), ("g5_step_trace.npz", 1),
+                                        # G10: the remaining CMO heads ('linear', 'mlp_byol'), which the reference leaves untrained
+                                        ("g10_step_trace_heads.npz", 0), ("g10_step_trace_heads.npz", 1)])
+def test_step_trace_matches_reference(golden_dir, fixture, ci):
     torch.set_num_threads(1)
-    g = np.load(os.path.join(golden_dir, "g5_step_trace.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     p = f"c{ci}_"
     head = str(g[p + "head"])
     feat_dim = 64 if head == "None" else 32
@@ -60,6 +62,18 @@ def test_step_trace_matches_reference(golden_dir, ci):
                                rtol=1e-4, atol=1e-5)
     # atts_k is in the optimizer but never gets a gradient -> not even weight decay touches it
     assert np.array_equal(cmo.atts_k.proj.weight.detach().numpy(), g[p + "kd_final.atts_k.proj.weight"])
+    if fixture.startswith("g10"):
+        # heads other than 'mlp' are not registered with the optimizer (reference train_student_moma.py:339-343): weights as
+        # initialised; the BatchNorm1d layers of 'mlp_byol' stay in training mode and their running statistics move
+        final = _sd(g, p + "kd_final.")
+        for name, t in cmo.state_dict().items():
+            if not name.startswith("embed_"):
+                continue
+            if "running" in name or "num_batches" in name:
+                np.testing.assert_allclose(t.numpy(), final[name].numpy(), rtol=1e-4, atol=1e-6)
+                assert not np.array_equal(final[name].numpy(), g[p + "kd." + name])
+            else:
+                assert np.array_equal(t.numpy(), final[name].numpy()) and np.array_equal(t.numpy(), g[p + "kd." + name])
 
 
 def test_step_trace_big_queue_matches_reference(golden_dir):
