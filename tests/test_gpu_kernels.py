@@ -430,7 +430,9 @@ def test_mha_fused_core_no_grad(ops, N, d, H):
 
 
 @pytest.mark.parametrize("N,d,H", [(256, 512, 4), (33, 128, 8), (129, 256, 2), (300, 512, 4), (77, 192, 4), (64, 64, 4),
-                                   (256, 1280, 4), (130, 2048, 4), (37, 320, 2), (250, 288, 1)])
+                                   (256, 1280, 4), (130, 2048, 4), (37, 320, 2), (250, 288, 1),
+                                   # wide heads whose last segment is a single 16-column k-step (144 = 128 + 16, 272 = 256 + 16)
+                                   (100, 288, 2), (64, 1088, 4)])
 def test_mha_fused_bwd_peaked(ops, N, d, H):
     """Fused per-head backward core (bf16 policy): peaked softmax rows (large q / k weights) so that a wrong pairing of
     tile rows between the two MFMA products of dQ / dK / dV cannot hide behind near-uniform attention; ragged N, head
