@@ -644,11 +644,13 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // (nothing else is left to hide there; done after the loop the 256 accumulator reads, 128 conversions and 32 stores
         // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
         {
+            // (a wave whose 32 rows all lie past B -- small or ragged batches -- multiplied zeros: nothing of it is read back)
+            const bool live = bt * QROWS_WG + wave * 32 < B;
             uint4* dst = opart_dst();
             pv(std::false_type{}, slot(t1 - 1), pa, [&](int) __attribute__((always_inline)) {}, [&](int c) __attribute__((always_inline)) {
-                if (c >= 1) store_tile(dst, c - 1);
+                if (c >= 1 && live) store_tile(dst, c - 1);
             });
-            store_tile(dst, NCT - 1);
+            if (live) store_tile(dst, NCT - 1);
         }
     } else {
         // ---- plain loop (forward-only and slab variants): score, softmax, (P.K), one tile at a time
@@ -1374,6 +1376,8 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
     __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
     const int tid = threadIdx.x;
     const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;
+    if (wb * 32 + opart_row(g, h, 0, 0) >= B) return;                    // all 8 rows of this block lie past B (pad rows: their
+                                                                         // partials are not even written by the passes over the queue)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     auto row_of = [&](int i) { return wb * 32 + opart_row(g, h, i >> 1, i & 1); };
     auto sum32 = [](float v) {
