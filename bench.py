@@ -317,7 +317,7 @@ def main():
         opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if distributed:
         from moma_amd.learning.ddp import wrap_student
-        ddp_s = wrap_student(model_s, device_ids=[local])
+        ddp_s = wrap_student(model_s, device_ids=[local])          # MOMA_DP=ddp keeps the stock reducer
         opt.gpu = local
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()
@@ -491,8 +491,12 @@ def main():
                            "replica_checksum_spread": {"student": spread[0], "criterion": spread[1], "ema_teacher": spread[2]},
                            "criterion_allreduce_launches": int(getattr(trainer, "grad_sync_launches", 0)),
                            "overlap_teacher": bool(opt.overlap_teacher), "graph_teacher": bool(getattr(opt, "graph_teacher", True)),
-                           "collective": "DDP bucketed gradient all-reduce (student) + one flat async all-reduce of the "
-                                         "trainable criterion modules per step; per-rank queue, no data-path gather"}
+                           "dp_wrap": type(ddp_s).__name__,
+                           "collective": ("ONE flat gradient all-reduce per step (student + trainable criterion modules) behind the "
+                                          "backward + one flat buffer broadcast per forward; per-rank queue, no data-path gather")
+                           if type(ddp_s).__name__ == "FlatDataParallel" else
+                           ("DDP bucketed gradient all-reduce (student) + one flat async all-reduce of the "
+                            "trainable criterion modules per step; per-rank queue, no data-path gather")}
         log(f"timed region: {dt:.2f} s; {out['value']} images/sec")
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU restatement (bounded sample) ...")

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 
 from .util import AverageMeter, accuracy
+from ..learning.contrast_trainer import ContrastTrainer
+from ..learning.ddp import FlatDataParallel
 
 
 def _set_bn_train(m):
@@ -57,9 +59,19 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
     ema_ok = None
     mocoatt = getattr(opt, "mem", "MoCo") == "MoCoAtt"
     attn_in_shuffle = opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix") and not mocoatt
-    sync_criterion = opt.distill == "moma" and (getattr(opt, "world_size", 1) > 1 or getattr(trainer, "grad_sync_single_rank", False))
-    if sync_criterion:
-        # one flat all-reduce per step for the trainable criterion modules, launched from autograd hooks (overlaps backward)
+    single_rank = bool(getattr(trainer, "grad_sync_single_rank", False))
+    sync_criterion = opt.distill == "moma" and (getattr(opt, "world_size", 1) > 1 or single_rank)
+    flat_dp = isinstance(model_s, FlatDataParallel)
+    flat_params = None
+    if flat_dp:
+        # learning/ddp.py: ONE flat all-reduce per step behind the backward -- the student's gradients and those of the trainable
+        # criterion modules (atts_q / embed_s: not under any wrapper, un-synchronised in the reference)
+        flat_params = model_s.grad_params()
+        if opt.distill == "moma":
+            flat_params = flat_params + [p for p in criterion_kd.parameters() if p.requires_grad]
+    elif sync_criterion:
+        # stock DDP on the student: one flat all-reduce per step for the trainable criterion modules, launched from autograd
+        # hooks (overlaps the backward)
         trainer.attach_grad_sync([p for p in criterion_kd.parameters() if p.requires_grad])
     # the teacher's two no-grad forwards per step are replayed from a HIP graph after a few eager calls
     # (opt.graph_teacher, default on for GPU runs; see helper/graphs.py); everything else uses `model_t` itself
@@ -204,7 +216,11 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
             scaler.scale(loss).backward()
         else:
             loss.backward()
-        if sync_criterion:
+        if flat_dp:
+            n_red = ContrastTrainer.allreduce_grads(flat_params, single_rank=single_rank, group=model_s.group)
+            if trainer is not None and n_red:
+                trainer.grad_sync_launches = getattr(trainer, "grad_sync_launches", 0) + n_red
+        elif sync_criterion:
             trainer.finish_grad_sync()                  # atts_q / embed_s are not under DDP (fixes Q7)
         if scaler is not None:
             scaler.step(optimizer)

@@ -225,14 +225,22 @@ class ContrastTrainer(BaseTrainer):
         self._gs_seen, self._gs_work, self._gs_flat = 0, None, None
 
     @staticmethod
-    def allreduce_grads(params):
-        """Blocking form of the same reduction (kept for callers without hooks)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        grads = [p.grad for p in params if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat.div_(dist.get_world_size())
-        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    def allreduce_grads(params, single_rank=False, group=None):
+        """ONE flat all-reduce (average) over the gradients of `params`, issued behind the backward: a concatenation, the
+        collective, a multi-tensor copy back.  The step's collective under `learning/ddp.py:FlatDataParallel` (student +
+        trainable criterion modules).  single_rank: run it on a one-rank group too (the rehearsal of the collective path)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        world = dist.get_world_size(group)
+        if world == 1 and not single_rank:
+            return 0
+        by_kind = {}
+        for p in params:
+            if p.grad is not None:
+                by_kind.setdefault((p.grad.dtype, p.grad.device), []).append(p.grad)
+        for grads in by_kind.values():                      # (one group in practice: every gradient here is fp32)
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, group=group)
+            flat.div_(world)
+            torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        return len(by_kind)

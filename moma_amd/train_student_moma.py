@@ -109,6 +109,8 @@ def build_parser():
     p.add_argument("--amp", default=None, choices=["bf16", "fp16"], help="autocast dtype for the backbones")
     p.add_argument("--channels_last", action="store_true")
     p.add_argument("--shuffle_bn", default="per_rank", choices=["per_rank", "gather"])
+    p.add_argument("--dp", default=None, choices=["flat", "ddp"],
+                   help="student wrap at world size > 1: one flat gradient all-reduce per step (default) or stock DDP")
     p.add_argument("--no_fused", action="store_true", help="reference call sequence on materialised logits")
     p.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic loader length")
     p.add_argument("--num_heads", type=int, default=4)
@@ -272,7 +274,7 @@ def main_worker(gpu, ngpus_per_node, opt):
         trainer.broadcast_memory(contrast)                       # optional step: synchronize memory (:336)
     if opt.multiprocessing_distributed:
         from .learning.ddp import wrap_student
-        ddp_s = wrap_student(model_s, device_ids=[opt.gpu] if device.type == "cuda" else None)
+        ddp_s = wrap_student(model_s, device_ids=[opt.gpu] if device.type == "cuda" else None, mode=getattr(opt, "dp", None))
         module_list = [ddp_s] + [m for m in list(module_list)[1:]]
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")

@@ -70,7 +70,7 @@ def _install_cpu_standins():
     ops.mha_group, ops.infonce_logits = mha_group, infonce_logits
 
 
-def _worker(rank, world, port, shuffle_mode, out):
+def _worker(rank, world, port, shuffle_mode, out, dp="flat"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -99,7 +99,7 @@ def _worker(rank, world, port, shuffle_mode, out):
     trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
     optimizer = torch.optim.SGD(trainable.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
     from moma_amd.learning.ddp import wrap_student
-    ddp = wrap_student(ms)                                  # the product's wrap: stock reducer + flat buffer broadcast
+    ddp = wrap_student(ms, mode=dp)                         # the product's wrap (default: FlatDataParallel; 'ddp' = stock reducer)
     mods = [ddp, mt]
     crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
     g = torch.Generator().manual_seed(100 + rank)          # different data shard per rank
@@ -123,10 +123,10 @@ def _worker(rank, world, port, shuffle_mode, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shuffle_mode", ["per_rank", "gather"])
-def test_two_rank_data_parallel(tmp_path, shuffle_mode):
+@pytest.mark.parametrize("shuffle_mode,dp", [("per_rank", "flat"), ("gather", "flat"), ("per_rank", "ddp")])
+def test_two_rank_data_parallel(tmp_path, shuffle_mode, dp):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, shuffle_mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, shuffle_mode, str(tmp_path), dp), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     B, K = 4, 24
     # replicas stay in sync: student through DDP, criterion modules through the explicit flat all-reduce
@@ -214,40 +214,55 @@ def _wrap_worker(rank, world, port, out):
         torch.manual_seed(3)
         return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1),
                              nn.BatchNorm2d(8), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(8, 5))
-    a, b = net(), net()
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    a, b, c = net(), net(), net()
+    if rank == 1:                                                        # replicas must START from rank 0 (the wraps broadcast)
+        with torch.no_grad():
+            for m in (a, b, c):
+                for p in m.parameters():
+                    p.add_(0.123)
     stock = nn.parallel.DistributedDataParallel(a)                       # the reference's wrap (stock defaults)
-    ours = wrap_student(b)
-    oa, ob = torch.optim.SGD(a.parameters(), lr=0.1, momentum=0.9), torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9)
+    ours = wrap_student(b, mode="ddp")                                   # stock reducer + flat buffer broadcast
+    flat = wrap_student(c, mode="flat")                                  # the default: ONE flat gradient all-reduce per step
+    opts = [torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9) for m in (a, b, c)]
     g = torch.Generator().manual_seed(50 + rank)                         # a different shard per rank
     for _ in range(3):
         x, y = torch.randn(6, 3, 8, 8, generator=g), torch.randint(0, 5, (6,), generator=g)
-        for m, o in ((stock, oa), (ours, ob)):
+        for m, o in zip((stock, ours, flat), opts):
             o.zero_grad(set_to_none=True)
             nn.functional.cross_entropy(m(x), y).backward()
+            if m is flat:
+                assert ContrastTrainer.allreduce_grads(flat.grad_params()) == 1
             o.step()
-    stock.eval(), ours.eval()
+    stock.eval(), ours.eval(), flat.eval()
     with torch.no_grad():                                                # one more forward (eval: no local update behind the
-        stock(x), ours(x)                                                # broadcast): both wraps leave rank 0's buffers everywhere
+        stock(x), ours(x), flat(x)                                       # broadcast): every wrap leaves rank 0's buffers everywhere
     res = dict(pa=[p.detach().clone() for p in a.parameters()], pb=[p.detach().clone() for p in b.parameters()],
-               ba=[t.clone() for t in a.buffers()], bb=[t.clone() for t in b.buffers()])
+               pc=[p.detach().clone() for p in c.parameters()],
+               ba=[t.clone() for t in a.buffers()], bb=[t.clone() for t in b.buffers()], bc=[t.clone() for t in c.buffers()])
     torch.save(res, os.path.join(out, f"w{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_student_wrap_equals_stock_ddp(tmp_path):
-    """learning/ddp.py:wrap_student (stock reducer + one flat buffer broadcast per dtype) against stock
-    DistributedDataParallel -- the reference's wrap, train_student_moma.py:345-349 -- on two gloo ranks with different shards:
-    parameters after three SGD steps and BatchNorm buffers (incl. the int64 batch counters) are the same, on both ranks."""
+    """learning/ddp.py:wrap_student -- mode 'flat' (the default: FlatDataParallel + ONE flat gradient all-reduce per step) and mode
+    'ddp' (stock reducer + one flat buffer broadcast per dtype) -- against stock DistributedDataParallel, the reference's wrap
+    (train_student_moma.py:345-349), on two gloo ranks with different shards and DIFFERENT initial weights on rank 1: parameters
+    after three SGD steps and BatchNorm buffers (incl. the int64 batch counters) are the same, on both ranks."""
     world, port = 2, _free_port()
     mp.spawn(_wrap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
     for r in (r0, r1):
-        for pa, pb in zip(r["pa"], r["pb"]):
+        for pa, pb, pc in zip(r["pa"], r["pb"], r["pc"]):
             assert torch.allclose(pa, pb, rtol=0, atol=1e-7)
-        for ba, bb in zip(r["ba"], r["bb"]):
+            assert torch.allclose(pa, pc, rtol=0, atol=2e-7)             # (sum, then divide -- the reducer divides, then sums)
+        for ba, bb, bc in zip(r["ba"], r["bb"], r["bc"]):
             assert torch.equal(ba, bb)
-    for b0, b1 in zip(r0["bb"], r1["bb"]):
-        assert torch.equal(b0, b1)                                       # rank 0's statistics everywhere
-    for p0, p1 in zip(r0["pb"], r1["pb"]):
-        assert torch.equal(p0, p1)
+            assert torch.allclose(ba.float(), bc.float(), rtol=0, atol=2e-7)
+    for key in ("bb", "bc"):
+        for b0, b1 in zip(r0[key], r1[key]):
+            assert torch.equal(b0, b1)                                   # rank 0's statistics everywhere
+    for key in ("pb", "pc"):
+        for p0, p1 in zip(r0[key], r1[key]):
+            assert torch.equal(p0, p1)                                   # replicas identical

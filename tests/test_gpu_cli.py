@@ -161,17 +161,19 @@ def test_bench_two_ranks_on_one_gpu_replicas_stay_in_sync(tmp_path):
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}, d
 
 
-def test_bench_one_rank_on_rccl(tmp_path):
+@pytest.mark.parametrize("dp", ["flat", "ddp"])
+def test_bench_one_rank_on_rccl(tmp_path, dp):
     """The N > 1 code path on RCCL ITSELF with the one rank a one-GPU box allows: torchrun -> bench.py with
-    MOMA_BENCH_FORCE_DIST=1 -> init_process_group("nccl") (communicator + watchdog thread live), DDP reducer on the student, the
-    hook-launched flat all-reduce of the criterion gradients issued on the same communicator, HIP-graph capture of the teacher
-    and the side stream, all ON.  Must finish, report the dist fields with backend nccl, and time like the plain run does
+    MOMA_BENCH_FORCE_DIST=1 -> init_process_group("nccl") (communicator + watchdog thread live); dp = flat: the default wrap (one
+    flat buffer broadcast per forward, ONE flat gradient all-reduce per step); dp = ddp: the stock reducer on the student with the
+    hook-launched flat all-reduce of the criterion gradients issued on the same communicator; HIP-graph capture of the teacher
+    and the side stream ON in both.  Must finish, report the dist fields with backend nccl, and time like the plain run does
     (no step more than 3x the median: a capture that collides with the watchdog or a blocked collective shows up there)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MOMA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MOMA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MOMA_DP=dp)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "5",
            "--batch_size", "64", "--image_size", "96", "--nce_k", "8192", "--no_cpu_baseline"]
@@ -180,6 +182,7 @@ def test_bench_one_rank_on_rccl(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     d = out["dist"]
     assert d["world_size"] == 1 and d["backend"] == "nccl" and d["overlap_teacher"] and d["graph_teacher"]
+    assert d["dp_wrap"] == {"flat": "FlatDataParallel", "ddp": "DistributedDataParallel"}[dp]
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}
     assert d["criterion_allreduce_launches"] == 5 + 8           # one flat all-reduce per warm-up and timed step
     assert out["ms_per_step_max"] < 3.0 * out["ms_per_step_median"], out
