@@ -10,7 +10,8 @@ and launch lines carry over.  What differs:
   * one process per GPU either through torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) or, as in the
     reference, `--multiprocessing-distributed` + mp.spawn; the backend string 'nccl' is RCCL on ROCm;
   * new optional flags: --moma_prec, --queue_dtype, --amp, --channels_last, --shuffle_bn, --no_fused,
-    --steps_per_epoch, --num_heads.
+    --steps_per_epoch, --num_heads, --dp (student wrap at world size > 1: flat = one gradient all-reduce per step, the
+    default; ddp = stock DistributedDataParallel as in the reference).
 """
 from __future__ import print_function
 
