@@ -58,6 +58,7 @@ def parse():
     p.add_argument("--amp", default="bf16", choices=["none", "bf16", "fp16"])
     p.add_argument("--channels_last", action="store_true",
                    help="NHWC backbones (MIOpen's depthwise backward is ~7x slower in NHWC on gfx950: off by default)")
+    p.add_argument("--learning_rate", type=float, default=0.05)
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_batch", type=int, default=16)
     p.add_argument("--cpu_steps", type=int, default=15)    # ~10 s of host work at B=16
@@ -202,7 +203,7 @@ def make_opt(a, rank, world):
         multiprocessing_distributed=world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1", print_freq=10 ** 9, batch_size=a.batch_size, rank=rank,
         world_size=world, model_s=a.model, model_t=a.model_t or a.model, std_pre=None, tec_pre=None, path_t=None,
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
-        learning_rate=0.05, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
+        learning_rate=a.learning_rate, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
         shuffle_bn="per_rank", num_heads=a.num_heads,
         # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
@@ -280,8 +281,44 @@ def heartbeat(period=60.0):
     threading.Thread(target=run, daemon=True).start()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) -- the reference's entry point spawns its own ranks too (train_student_moma.py:215-224,
+    mp.spawn).  This parent never touches the GPU; it relays the children's stderr, prints rank 0's JSON line and returns
+    their exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    if os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1":
+        have = torch.cuda.device_count()            # (counts devices without initialising the runtime)
+        if have < n:
+            log(f"--gpus {n} but only {have} GPU(s) visible")
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    log(f"no launcher in the environment: starting {n} ranks: {' '.join(cmd)}")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)       # stderr is inherited (progress lines stream through)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        log(f"launcher exited with code {r.returncode}{'' if lines else ' and no JSON line'}")
+        return r.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a.gpus))       # before any GPU call in this process
     heartbeat()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -317,7 +354,9 @@ def main():
         opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if distributed:
         from moma_amd.learning.ddp import wrap_student
+        from moma_amd.learning.ddp import broadcast_module_state
         ddp_s = wrap_student(model_s, device_ids=[local])          # MOMA_DP=ddp keeps the stock reducer
+        broadcast_module_state([criterion_list[2], model_t])       # (under no wrap: identical by seed in the reference)
         opt.gpu = local
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()
@@ -380,7 +419,7 @@ def main():
     t0 = time.perf_counter()
     e_start.record()
     with quiet:
-        train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
+        _acc, loss_avg = train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
     barrier()
     dt = time.perf_counter() - t0
     rec.enabled = False
@@ -396,10 +435,28 @@ def main():
     if rank == 0 and step_gpu:
         log("per-step ms (gpu | host issue): " + " ".join(f"{g:.1f}|{h:.1f}" for g, h in zip(step_gpu, step_host)))
 
+    # a timed region whose loss is not finite measured a broken step (round 3 saw one produce a normal-looking line): no line
+    import math
+    bad = torch.tensor([0.0 if math.isfinite(loss_avg) else 1.0], device=dev)
+    if distributed:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if bad.item() != 0.0:
+        log(f"rank {rank}: mean loss of the timed steps is {loss_avg} -- a non-finite loss on some rank: no result line")
+        if distributed:
+            dist.destroy_process_group()
+        raise SystemExit(3)
+    med = lambda v: sorted(v)[len(v) // 2] if v else 0.0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     spread = None
+    per_rank = None
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # per-rank view of the timed region: median step (GPU / host issue), the step's collective and the buffer broadcast
+        mine = torch.tensor([med(step_gpu), med(step_host), rec.mean_ms("dp_allreduce_grads") or 0.0,
+                             rec.mean_ms("dp_buffer_broadcast") or 0.0, loss_avg], device=dev, dtype=torch.float64)
+        rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+        per_rank = [[round(float(v), 3) for v in r.tolist()] for r in rows]
         # replicas must still be bit-identical: student (DDP all-reduce), trainable criterion modules (the hook-launched flat
         # all-reduce), EMA teacher (updated locally from identical student weights)
         def csum(mod):
@@ -473,6 +530,8 @@ def main():
             "ms_per_step_median": round(sorted(step_gpu)[len(step_gpu) // 2], 3) if step_gpu else None,
             "ms_per_step_max": round(max(step_gpu), 3) if step_gpu else None,
             "ms_first_step": round(step_gpu[0], 3) if step_gpu else None,
+            "host_issue_ms_median": round(med(step_host), 3) if step_host else None,
+            "loss_mean_timed_steps": round(loss_avg, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{2 if a.model.startswith('vit_small') else 1}]: {a.model} student+teacher" if (a.model_t or a.model) == a.model else
@@ -487,7 +546,15 @@ def main():
             "roofline": roof,
         }
         if distributed:      # what the N>1 line was measured with (the driver checks it against its own launch)
+            cols = list(zip(*per_rank))
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "per_rank_ms_per_step_median": list(cols[0]), "per_rank_host_issue_ms_median": list(cols[1]),
+                           "per_rank_allreduce_grads_ms": list(cols[2]), "per_rank_buffer_broadcast_ms": list(cols[3]),
+                           "per_rank_loss": list(cols[4]),
+                           "timing_note": "HIP events on the rank's main stream around FlatDataParallel.allreduce_grads (cat + the "
+                                          "collective + copy back; includes waiting for the slowest rank to arrive) and around the "
+                                          "flat buffer broadcast in front of the student forward; host issue = wall time the host "
+                                          "spent issuing a step; 0.0 = that path did not run (MOMA_DP=ddp: the reducer's buckets)",
                            "replica_checksum_spread": {"student": spread[0], "criterion": spread[1], "ema_teacher": spread[2]},
                            "criterion_allreduce_launches": int(getattr(trainer, "grad_sync_launches", 0)),
                            "overlap_teacher": bool(opt.overlap_teacher), "graph_teacher": bool(getattr(opt, "graph_teacher", True)),

@@ -217,7 +217,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         else:
             loss.backward()
         if flat_dp:
-            n_red = ContrastTrainer.allreduce_grads(flat_params, single_rank=single_rank, group=model_s.group)
+            n_red = model_s.allreduce_grads(flat_params, single_rank=single_rank)
             if trainer is not None and n_red:
                 trainer.grad_sync_launches = getattr(trainer, "grad_sync_launches", 0) + n_red
         elif sync_criterion:

@@ -226,9 +226,9 @@ class ContrastTrainer(BaseTrainer):
 
     @staticmethod
     def allreduce_grads(params, single_rank=False, group=None):
-        """ONE flat all-reduce (average) over the gradients of `params`, issued behind the backward: a concatenation, the
-        collective, a multi-tensor copy back.  The step's collective under `learning/ddp.py:FlatDataParallel` (student +
-        trainable criterion modules).  single_rank: run it on a one-rank group too (the rehearsal of the collective path)."""
+        """ONE flat all-reduce (average) over the gradients of `params` on the default / given group -- the stateless form of
+        `learning/ddp.py:FlatDataParallel.allreduce_grads` (which also verifies that the ranks reduce the same gradient set;
+        the loop calls that one).  -> number of collectives launched."""
         if not (dist.is_available() and dist.is_initialized()):
             return 0
         world = dist.get_world_size(group)

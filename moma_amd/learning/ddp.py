@@ -8,19 +8,33 @@ EfficientNet-B0, rocprofv3 kernel trace of `MOMA_BENCH_FORCE_DIST=1 bench.py`: +
     set_to_none=True)`, the reference's call, hands it fresh gradient tensors every step; with a communication hook they become
     213 plain copies) -- to overlap an all-reduce of 16 MB that takes ~0.3 ms on xGMI with a 40 ms step;
   * `broadcast_buffers=True` copies each buffer back with one memcpy PER BUFFER (147 launches).
-`FlatDataParallel` (the default) does neither: the buffers travel as one flat tensor per dtype, and the step's gradients --
-student AND the trainable criterion modules, which the reference leaves un-synchronised -- are reduced by ONE flat
-all-reduce behind the backward (`ContrastTrainer.allreduce_grads`: a concatenation, the collective, a multi-tensor copy back):
-one collective per step at a fixed point of the program, nothing issued from autograd hooks, nothing to order against a
-reducer.  `wrap_student(..., mode="ddp")` (`--dp ddp`, `MOMA_DP=ddp`) keeps the stock reducer with the flat buffer broadcast.
+`FlatDataParallel` does neither: the buffers travel as one flat tensor per dtype, and the step's gradients -- student AND the
+trainable criterion modules, which the reference leaves un-synchronised -- are reduced by ONE flat all-reduce behind
+the backward (`FlatDataParallel.allreduce_grads`: a concatenation, the collective, a multi-tensor copy back): one collective
+per step at a fixed point of the program, nothing issued from autograd hooks, nothing to order against a reducer -- which is
+also what lets the student's forward + backward live in a HIP graph (helper/step_graph.py).
+
+What the stock wrap checks and this one has to check itself:
+  * construction: every rank must hold the same parameter / buffer list (count, shapes, dtypes) -- `_verify_replicas`, one
+    all_gather of a fingerprint, RuntimeError on every rank on a mismatch (DDP: `_verify_param_shape_across_processes`);
+  * first contact with a communicator: `collective_self_test` runs the two collectives the wrap uses (flat broadcast, flat
+    sum all-reduce) on a known pattern and compares with the closed form.  `wrap_student(mode=None)` = "auto": flat when the
+    self-test passes, the stock reducer (with a notice) when it does not;
+  * every step: the set of gradients that goes into the flat buffer must be the same on every rank or the collective's sizes
+    differ (a hang, or silent corruption).  The (count, element total, index hash) of the set is exchanged whenever it CHANGES
+    on a rank (first step, a head un-frozen later) and a mismatch raises on every rank; an unchanged set costs nothing.
+`wrap_student(..., mode="ddp")` (`--dp ddp`, `MOMA_DP=ddp`) keeps the stock reducer with the flat buffer broadcast.
 """
 from __future__ import annotations
 
 import os
+import zlib
 
 import torch
 import torch.distributed as dist
 from torch import nn
+
+from .. import ops
 
 
 def _flat_broadcast(tensors, group=None):
@@ -37,28 +51,89 @@ def _flat_broadcast(tensors, group=None):
             torch._foreach_copy_(ts, [v.view_as(t) for v, t in zip(flat.split([t.numel() for t in ts]), ts)])
 
 
+def _fingerprint(tensors) -> list:
+    """(count, element total, crc of the shape / dtype list) of a tensor list -- what has to agree across the ranks"""
+    desc = ";".join(f"{tuple(t.shape)}:{t.dtype}" for t in tensors)
+    return [len(tensors), sum(t.numel() for t in tensors), zlib.crc32(desc.encode())]
+
+
+def _all_agree(values, device, group=None, what="replicas"):
+    """all_gather of a small int64 vector; RuntimeError ON EVERY RANK when the ranks do not hold the same one"""
+    mine = torch.tensor(values, dtype=torch.int64, device=device)
+    world = dist.get_world_size(group)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    rows = [g.tolist() for g in got]
+    if any(r != rows[0] for r in rows):
+        raise RuntimeError(f"data-parallel {what} differ across ranks (count, elements, layout hash per rank): {rows}")
+
+
+def broadcast_module_state(modules, group=None):
+    """rank 0's parameters AND buffers of `modules` -> every rank, one flat broadcast per dtype.  The student gets this from its
+    wrap; the trainable criterion modules (atts_q, embed_s) and the EMA teacher are not under any wrap -- in the reference they
+    agree across ranks only because every rank seeds identically (train_student_moma.py:241-246)."""
+    ts = []
+    for m in modules:
+        if m is not None:
+            ts += list(m.parameters()) + list(m.buffers())
+    if ts and dist.is_available() and dist.is_initialized():
+        _all_agree(_fingerprint(ts), ts[0].device, group, "module states")
+        _flat_broadcast(ts, group)
+
+
+def collective_self_test(device, group=None) -> bool:
+    """The wrap's two collectives on a known pattern, on the live communicator: a flat broadcast of rank 0's ramp and a flat sum
+    all-reduce of (rank + 1) * ramp, compared with the closed form on every rank; the verdicts are AND-ed over the ranks (a MIN
+    all-reduce), so every rank returns the same answer."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = 1 << 16
+    ramp = torch.arange(n, device=device, dtype=torch.float32) % 251.0
+    a = [torch.full((7,), float(rank + 1), device=device), (ramp * (rank + 1)).clone(), torch.full((3, 5), -float(rank), device=device)]
+    _flat_broadcast(a, group)
+    ok = bool(torch.equal(a[0], torch.full((7,), 1.0, device=device)) and torch.equal(a[1], ramp) and
+              torch.equal(a[2], torch.zeros(3, 5, device=device)))
+    flat = torch.cat([(ramp * (rank + 1)), torch.full((13,), float(rank + 1), device=device)])
+    dist.all_reduce(flat, group=group)
+    s = world * (world + 1) / 2.0
+    ok = ok and bool(torch.equal(flat[:n], ramp * s) and torch.equal(flat[n:], torch.full((13,), s, device=device)))
+    verdict = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    return bool(verdict.item() == 1)
+
+
 class FlatBufferBroadcast:
-    """Forward pre-hook: rank 0's module buffers -> every rank (what DDP's `broadcast_buffers` does per forward)."""
+    """Forward pre-hook: rank 0's module buffers -> every rank (what DDP's `broadcast_buffers` does per forward).  The buffer
+    list is taken at wrap time (as the stock reducer's is); `refresh()` re-reads it after a module surgery."""
 
     def __init__(self, module: nn.Module, group=None):
         self.group = group
-        self.buffers = [b for b in module.buffers() if b is not None and b.numel() > 0]
+        self.module = module
+        self.refresh()
+
+    def refresh(self):
+        self.buffers = [b for b in self.module.buffers() if b is not None and b.numel() > 0]
 
     def __call__(self, _module=None, _args=None):
         if self.buffers:
-            _flat_broadcast(self.buffers, self.group)
+            with ops._timed("dp_buffer_broadcast"):
+                _flat_broadcast(self.buffers, self.group)
 
 
 class FlatDataParallel(nn.Module):
     """`.module` + a forward that first broadcasts the buffers; the gradients are reduced by the training loop with ONE flat
-    all-reduce per step (`ContrastTrainer.allreduce_grads(flat_dp.grad_params() + criterion parameters)`)."""
+    all-reduce per step (`flat_dp.allreduce_grads(flat_dp.grad_params() + criterion parameters)`)."""
 
     def __init__(self, module: nn.Module, group=None):
         super().__init__()
         self.module = module
         self.group = group
-        _flat_broadcast(list(module.parameters()) + list(module.buffers()), group)      # replicas start from rank 0 (as DDP's constructor)
+        state = list(module.parameters()) + list(module.buffers())
+        if state:
+            _all_agree(_fingerprint(state), state[0].device, group, "student replicas")     # as DDP's constructor verifies
+        _flat_broadcast(state, group)                                                        # replicas start from rank 0
         self.flat_buffer_broadcast = FlatBufferBroadcast(module, group)
+        self._grad_sig = None            # fingerprint of the gradient set the ranks last agreed on
+        self.allreduce_launches = 0
 
     def forward(self, *args, **kwargs):
         self.flat_buffer_broadcast()
@@ -67,13 +142,58 @@ class FlatDataParallel(nn.Module):
     def grad_params(self):
         return [p for p in self.module.parameters() if p.requires_grad]
 
+    def allreduce_grads(self, params, single_rank=False):
+        """ONE flat all-reduce (average) over the gradients of `params` (the student's and the trainable criterion modules'),
+        issued behind the backward.  -> number of collectives launched (0 without a group / at world size 1 unless
+        single_rank: the one-rank rehearsal of the collective path)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        world = dist.get_world_size(self.group)
+        if world == 1 and not single_rank:
+            return 0
+        by_kind, which = {}, []
+        for i, p in enumerate(params):
+            if p.grad is not None:
+                by_kind.setdefault((p.grad.dtype, p.grad.device), []).append(p.grad)
+                which.append(i)
+        if not which:
+            sig = (0, 0, 0)
+        else:
+            sig = (len(which), sum(params[i].grad.numel() for i in which), zlib.crc32(repr(which).encode()))
+        if sig != self._grad_sig:
+            # the set changed on THIS rank (first step; a module joined or left the backward): it must have changed on all of
+            # them, and to the same set -- otherwise the flat buffers differ in size
+            dev = params[which[0]].grad.device if which else next(self.module.parameters()).device
+            _all_agree(list(sig), dev, self.group, "gradient sets")
+            self._grad_sig = sig
+        with ops._timed("dp_allreduce_grads"):
+            for grads in by_kind.values():                      # (one group in practice: every gradient here is fp32)
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat, group=self.group)
+                flat.div_(world)
+                torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        self.allreduce_launches += len(by_kind)
+        return len(by_kind)
+
 
 def wrap_student(model: nn.Module, device_ids=None, group=None, mode: str | None = None) -> nn.Module:
-    mode = mode or os.environ.get("MOMA_DP", "flat")
+    """mode: 'flat' | 'ddp' | None = MOMA_DP from the environment, else 'auto' (flat if the collectives pass their self-test
+    on this communicator, else the stock reducer)."""
+    mode = mode or os.environ.get("MOMA_DP", "auto")
+    if mode == "auto":
+        dev = next(model.parameters()).device
+        try:
+            ok = collective_self_test(dev, group)
+        except Exception as e:                                   # a backend that cannot run one of the two collectives
+            print(f"[moma] flat data-parallel self-test raised {type(e).__name__}: {e}")
+            ok = False
+        mode = "flat" if ok else "ddp"
+        if not ok and dist.get_rank() == 0:
+            print("[moma] flat data-parallel self-test FAILED on this communicator: falling back to the stock DDP reducer")
     if mode == "flat":
         return FlatDataParallel(model, group)
     if mode != "ddp":
-        raise ValueError(f"unknown data-parallel mode {mode!r} (flat | ddp)")
+        raise ValueError(f"unknown data-parallel mode {mode!r} (flat | ddp | auto)")
     ddp = nn.parallel.DistributedDataParallel(model, device_ids=device_ids, gradient_as_bucket_view=True, broadcast_buffers=False,
                                               process_group=group)
     sync = FlatBufferBroadcast(model, group)

@@ -232,7 +232,7 @@ def _wrap_worker(rank, world, port, out):
             o.zero_grad(set_to_none=True)
             nn.functional.cross_entropy(m(x), y).backward()
             if m is flat:
-                assert ContrastTrainer.allreduce_grads(flat.grad_params()) == 1
+                assert flat.allreduce_grads(flat.grad_params()) == 1
             o.step()
     stock.eval(), ours.eval(), flat.eval()
     with torch.no_grad():                                                # one more forward (eval: no local update behind the
@@ -266,3 +266,69 @@ def test_student_wrap_equals_stock_ddp(tmp_path):
     for key in ("pb", "pc"):
         for p0, p1 in zip(r0[key], r1[key]):
             assert torch.equal(p0, p1)                                   # replicas identical
+
+
+def _safety_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moma_amd.learning.ddp import (FlatDataParallel, broadcast_module_state, collective_self_test, wrap_student)
+    res = {}
+    # (1) the wrap's two collectives pass their self-test on this communicator; mode None / 'auto' then picks the flat wrap
+    res["self_test"] = collective_self_test(torch.device("cpu"))
+    torch.manual_seed(rank)
+    res["auto_is_flat"] = isinstance(wrap_student(nn.Linear(4, 3), mode="auto"), FlatDataParallel)
+    # (2) replicas with different layouts are refused at construction, on every rank
+    try:
+        FlatDataParallel(nn.Linear(4, 3 + rank))
+        res["layout_refused"] = False
+    except RuntimeError as e:
+        res["layout_refused"] = "differ across ranks" in str(e)
+    # (3) modules under no wrap (criterion, teacher): rank 0's state everywhere
+    torch.manual_seed(10 + rank)
+    m = nn.Sequential(nn.Linear(5, 5), nn.BatchNorm1d(5))
+    m[1].running_mean.fill_(float(rank + 1))
+    broadcast_module_state([m, None])
+    res["state"] = torch.cat([t.detach().reshape(-1).double() for t in list(m.parameters()) + list(m.buffers())])
+    # (4) a gradient set that differs across the ranks raises on every rank instead of reducing buffers of different sizes
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 2))
+    flat = FlatDataParallel(net)
+    extra = nn.Linear(4, 1)                      # a "criterion module": receives a gradient on rank 1 only
+    x = torch.randn(3, 4)
+    loss = flat(x).sum() + (extra(x).sum() if rank == 1 else 0.0)
+    loss.backward()
+    params = flat.grad_params() + list(extra.parameters())
+    try:
+        flat.allreduce_grads(params)
+        res["gradset_refused"] = False
+    except RuntimeError as e:
+        res["gradset_refused"] = "gradient sets differ" in str(e)
+    # (5) same set on both ranks: one collective, averaged; an unchanged set is not re-verified
+    for p in params:
+        p.grad = None
+    (flat(x * (rank + 1)).sum() + extra(x * (rank + 1)).sum()).backward()
+    local = [p.grad.clone() for p in params]
+    res["n_coll"] = flat.allreduce_grads(params)
+    sig = flat._grad_sig
+    gathered = [[torch.empty_like(g) for _ in range(world)] for g in local]
+    for g, dst in zip(local, gathered):
+        dist.all_gather(dst, g)
+    res["avg_ok"] = all(torch.allclose(p.grad, sum(dst) / world, atol=1e-6) for p, dst in zip(params, gathered))
+    res["sig_kept"] = flat._grad_sig == sig and sig[0] == len(params)
+    torch.save(res, f"{out}.rank{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_wrap_safety_checks(tmp_path):
+    """ADVICE r3 (learning/ddp.py): what stock DDP verifies and the flat wrap has to verify itself -- identical replica layouts at
+    construction, identical gradient sets before the flat all-reduce (a mismatch raises on EVERY rank instead of hanging or
+    corrupting), a self-test of the two collectives on the live communicator, and rank 0's state for the modules under no wrap."""
+    out = str(tmp_path / "safe")
+    mp.spawn(_safety_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")
+    for r in (r0, r1):
+        assert r["self_test"] and r["auto_is_flat"] and r["layout_refused"] and r["gradset_refused"]
+        assert r["n_coll"] == 1 and r["avg_ok"] and r["sig_kept"]
+    assert torch.equal(r0["state"], r1["state"]) and r0["state"][-11:-6].eq(1.0).all()     # rank 0's running_mean (rank 1 had 2.0); then var [5], count [1]

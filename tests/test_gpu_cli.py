@@ -136,29 +136,79 @@ def test_cli_config5_cross_arch_vit_base_to_resnet50_fp16(tmp_path):
     assert p["s_dim"] == 2048 and p["t_dim"] == 768 and p["feat_dim"] == 512
 
 
-def test_bench_two_ranks_on_one_gpu_replicas_stay_in_sync(tmp_path):
-    """The combination the driver's multi-GPU run hits first, rehearsed on ONE GPU: `python -m torch.distributed.run` with two
-    ranks -> bench.py --gpus 2 (gloo carries the collectives: RCCL refuses two ranks on one device), DDP + the hook-launched
-    flat all-reduce of the criterion gradients + HIP-graphed teacher + teacher side on a second stream, all ON.  After warm-up
-    and timed steps the replicas must be BIT-identical (student, criterion modules, EMA teacher) and the JSON line must carry
-    the N > 1 fields."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MOMA_BENCH_SAME_DEVICE="1", MOMA_BENCH_BACKEND="gloo", MOMA_BENCH_FORCE_OVERLAP="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
-           "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return port
+
+
+_SMALL = ["--steps", "6", "--warmup", "5", "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline"]
+
+
+def _check_two_rank_line(out, dp, steps=6, warmup=5):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak"
     d = out["dist"]
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["overlap_teacher"] and d["graph_teacher"]
-    assert d["criterion_allreduce_launches"] == 5 + 6
+    assert d["dp_wrap"] == {"flat": "FlatDataParallel", "ddp": "DistributedDataParallel"}[dp]
+    assert d["criterion_allreduce_launches"] == warmup + steps
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}, d
+    # per-rank view of the timed region (what an N = 8 line that misses its efficiency target has to explain itself with)
+    for key in ("per_rank_ms_per_step_median", "per_rank_host_issue_ms_median", "per_rank_allreduce_grads_ms",
+                "per_rank_buffer_broadcast_ms", "per_rank_loss"):
+        assert len(d[key]) == 2, key
+    assert all(v > 0 for v in d["per_rank_ms_per_step_median"] + d["per_rank_host_issue_ms_median"] + d["per_rank_buffer_broadcast_ms"])
+    assert all(np.isfinite(v) for v in d["per_rank_loss"]) and np.isfinite(out["loss_mean_timed_steps"])
+    if dp == "flat":
+        assert all(v > 0 for v in d["per_rank_allreduce_grads_ms"])
+    else:
+        assert d["per_rank_allreduce_grads_ms"] == [0.0, 0.0]          # the stock reducer's buckets: not under these events
+
+
+@pytest.mark.parametrize("dp", ["flat", "ddp"])
+def test_bench_two_ranks_on_one_gpu_replicas_stay_in_sync(tmp_path, dp):
+    """The combination the driver's multi-GPU run hits first, rehearsed on ONE GPU: `python -m torch.distributed.run` with two
+    ranks -> bench.py --gpus 2 (gloo carries the collectives: RCCL refuses two ranks on one device) with the HIP-graphed teacher
+    and the teacher side on a second stream ON, under both student wraps: dp = flat -- learning/ddp.py:FlatDataParallel, ONE flat
+    gradient all-reduce per step behind the backward + one flat buffer broadcast per forward; dp = ddp -- the stock reducer with
+    the criterion gradients' flat all-reduce launched from autograd hooks.  After warm-up and timed steps the replicas must be
+    BIT-identical (student, criterion modules, EMA teacher) and the JSON line must carry the N > 1 fields."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, MOMA_BENCH_SAME_DEVICE="1", MOMA_BENCH_BACKEND="gloo", MOMA_BENCH_FORCE_OVERLAP="1", MOMA_DP=dp)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + _SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _check_two_rank_line(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), dp)
+
+
+def test_bench_gpus2_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks (before any GPU call in the parent,
+    which only relays rank 0's JSON line and the exit code) -- as the reference's entry point spawns its ranks itself
+    (train_student_moma.py:215-224).  Default wrap (MOMA_DP unset = auto: the collectives' self-test picks the flat wrap)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOMA_DP")}
+    env.update(MOMA_BENCH_SAME_DEVICE="1", MOMA_BENCH_BACKEND="gloo", MOMA_BENCH_FORCE_OVERLAP="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + _SMALL, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines          # stdout carries exactly the one JSON line
+    _check_two_rank_line(json.loads(lines[0]), "flat")
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_refuses_a_non_finite_loss(tmp_path):
+    """A timed region whose loss is not finite measured a broken step: bench.py prints no result line and exits non-zero (round 3:
+    a development run with `Loss nan` produced a normal-looking JSON line).  Forced here by a learning rate of 1e30."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "3", "--batch_size", "32",
+                        "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline", "--learning_rate", "1e30"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 3, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")] and "non-finite loss" in r.stderr
 
 
 @pytest.mark.parametrize("dp", ["flat", "ddp"])
@@ -171,9 +221,8 @@ def test_bench_one_rank_on_rccl(tmp_path, dp):
     (no step more than 3x the median: a capture that collides with the watchdog or a blocked collective shows up there)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, MOMA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MOMA_DP=dp)
+    port = _free_port()
+    env = dict(os.environ, MOMA_BENCH_FORCE_DIST="1", MOMA_DP=dp)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "5",
            "--batch_size", "64", "--image_size", "96", "--nce_k", "8192", "--no_cpu_baseline"]

@@ -762,6 +762,24 @@ def test_dual_queue_memories_one_sweep(ops, cls_name, B, d, K):
     for a, b in zip(losses, s_losses):
         assert abs(a.item() - b.item()) < 2e-5 * max(1.0, abs(b.item()))
     assert (q.grad - q2.grad).abs().max().item() < 1e-3 * q2.grad.abs().max().item()
+    # (c) the oracle itself (oracle.moco_dual_forward -> infonce_loss / infonce_grad: MoMA/mem_moco.py:165-253 + CrossEntropy, numpy)
+    # on the pre-enqueue queues -- the anchor to the reference without any other product path in between
+    N = lambda t: t.detach().float().cpu().numpy()
+    o_ms, o_mt = N(single.memory_s), N(single.memory_t)
+    pre_s, pre_t = o_ms.copy(), o_mt.copy()
+    outs, _labels, o_index = O.moco_dual_forward(o_ms, o_mt, 0, N(q0), N(k), N(kt), 0.15, q_t=N(qt0) if n_terms == 4 else None)
+    assert len(outs) == n_terms and o_index == mem.index
+    for a, lg in zip(losses, outs):
+        b = O.infonce_loss(lg)["loss"]
+        assert abs(a.item() - b) < 1e-3 * max(1.0, abs(b)), (a.item(), b)
+    o_gq = O.infonce_grad(N(q0), N(k), pre_s, 0.15) + O.infonce_grad(N(q0), N(kt), pre_t, 0.15)
+    assert np.abs(N(q.grad) - o_gq).max() < 2e-2 * np.abs(o_gq).max()
+    if n_terms == 4:
+        o_gqt = O.infonce_grad(N(qt0), N(k), pre_s, 0.15) + O.infonce_grad(N(qt0), N(kt), pre_t, 0.15)
+        assert np.abs(N(qt.grad) - o_gqt).max() < 2e-2 * np.abs(o_gqt).max()
+    # the oracle's enqueued queues (fp32 rows) rounded to the product's bf16 storage: same rows in the same slots
+    assert torch.equal(mem.memory_s.cpu(), torch.from_numpy(o_ms).to(torch.bfloat16))
+    assert torch.equal(mem.memory_t.cpu(), torch.from_numpy(o_mt).to(torch.bfloat16))
 
 
 def test_mocoatt_cross_attention_variants_golden(ops, golden_dir):
