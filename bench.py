@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--cpu_batch", type=int, default=16)
     p.add_argument("--cpu_steps", type=int, default=15)    # ~10 s of host work at B=16
     p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
+    p.add_argument("--no_graph_student", dest="graph_student", action="store_false",
+                   help="issue the step launch by launch instead of replaying it from HIP graphs (helper/step_graph.py)")
     p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
                    help="queue the teacher / key side of the step on the main stream instead of a second HIP stream")
     return p.parse_args()
@@ -205,7 +207,7 @@ def make_opt(a, rank, world):
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=a.learning_rate, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
-        shuffle_bn="per_rank", num_heads=a.num_heads,
+        shuffle_bn="per_rank", num_heads=a.num_heads, graph_student=a.graph_student,
         # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
         overlap_teacher=a.overlap_teacher and (os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1" or
                                                os.environ.get("MOMA_BENCH_FORCE_OVERLAP") == "1"))
@@ -415,25 +417,32 @@ def main():
     barrier()
     log(f"warm-up done; timing {a.steps} steps")
     opt.step_events = []
+    sg = getattr(trainer, "_step_graphs", None)
+    replays0 = sg.replays if sg is not None else 0
     e_start = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     e_start.record()
     with quiet:
         _acc, loss_avg = train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
     barrier()
     dt = time.perf_counter() - t0
+    sg = getattr(trainer, "_step_graphs", None)
+    replayed = (sg.replays if sg is not None else 0) - replays0
     rec.enabled = False
     kev.enabled = False
     # per-step times: GPU = between the HIP events recorded at the end of consecutive steps (stream time, includes queueing
     # behind the previous step); host = when the host finished issuing the step
-    step_gpu, step_host, prev_e, prev_t = [], [], e_start, t0
-    for t_host, ev in opt.step_events:
+    # (host issue is WALL time: once the host is a few steps ahead it blocks on the full launch queue and the figure tends to
+    #  the GPU's step time; host cpu = CPU time of the issuing thread, what the step costs the host when nothing blocks it)
+    step_gpu, step_host, step_cpu, prev_e, prev_t, prev_c = [], [], [], e_start, t0, c0
+    for t_host, ev, t_cpu in opt.step_events:
         step_gpu.append(prev_e.elapsed_time(ev))
         step_host.append((t_host - prev_t) * 1e3)
-        prev_e, prev_t = ev, t_host
+        step_cpu.append((t_cpu - prev_c) * 1e3)
+        prev_e, prev_t, prev_c = ev, t_host, t_cpu
     opt.step_events = None
     if rank == 0 and step_gpu:
-        log("per-step ms (gpu | host issue): " + " ".join(f"{g:.1f}|{h:.1f}" for g, h in zip(step_gpu, step_host)))
+        log("per-step ms (gpu | host issue | host cpu): " + " ".join(f"{g:.1f}|{h:.1f}|{c:.1f}" for g, h, c in zip(step_gpu, step_host, step_cpu)))
 
     # a timed region whose loss is not finite measured a broken step (round 3 saw one produce a normal-looking line): no line
     import math
@@ -453,7 +462,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         # per-rank view of the timed region: median step (GPU / host issue), the step's collective and the buffer broadcast
         mine = torch.tensor([med(step_gpu), med(step_host), rec.mean_ms("dp_allreduce_grads") or 0.0,
-                             rec.mean_ms("dp_buffer_broadcast") or 0.0, loss_avg], device=dev, dtype=torch.float64)
+                             rec.mean_ms("dp_buffer_broadcast") or 0.0, loss_avg, med(step_cpu)], device=dev, dtype=torch.float64)
         rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(rows, mine)
         per_rank = [[round(float(v), 3) for v in r.tolist()] for r in rows]
@@ -531,6 +540,8 @@ def main():
             "ms_per_step_max": round(max(step_gpu), 3) if step_gpu else None,
             "ms_first_step": round(step_gpu[0], 3) if step_gpu else None,
             "host_issue_ms_median": round(med(step_host), 3) if step_host else None,
+            "host_issue_ms_min": round(min(step_host), 3) if step_host else None,
+            "host_cpu_ms_median": round(med(step_cpu), 3) if step_cpu else None,
             "loss_mean_timed_steps": round(loss_avg, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",
@@ -542,7 +553,8 @@ def main():
                                    f"alpha=0.999, T=0.15, SGD; backbones autocast={a.amp} (BN+SiLU / depthwise / SE on the library's helper "
                                    f"kernels: MOMA_BN={os.environ.get('MOMA_BN', 'hip')} MOMA_DW={os.environ.get('MOMA_DW', 'hip')} "
                                    f"MOMA_SE={os.environ.get('MOMA_SE', 'hip')}), KD kernels {a.moma_prec}",
-                       "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank"},
+                       "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank",
+                       "step_graphs": {"enabled": bool(a.graph_student), "timed_steps_replayed": int(replayed)}},
             "roofline": roof,
         }
         if distributed:      # what the N>1 line was measured with (the driver checks it against its own launch)
@@ -550,7 +562,7 @@ def main():
             out["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                            "per_rank_ms_per_step_median": list(cols[0]), "per_rank_host_issue_ms_median": list(cols[1]),
                            "per_rank_allreduce_grads_ms": list(cols[2]), "per_rank_buffer_broadcast_ms": list(cols[3]),
-                           "per_rank_loss": list(cols[4]),
+                           "per_rank_loss": list(cols[4]), "per_rank_host_cpu_ms_median": list(cols[5]),
                            "timing_note": "HIP events on the rank's main stream around FlatDataParallel.allreduce_grads (cat + the "
                                           "collective + copy back; includes waiting for the slowest rank to arrive) and around the "
                                           "flat buffer broadcast in front of the student forward; host issue = wall time the host "

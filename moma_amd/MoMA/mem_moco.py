@@ -120,7 +120,11 @@ class MoCo(BaseMoCo):
         if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
             shadow = self._bf16_shadow()
         loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack)
-        all_k = all_k if all_k is not None else k
+        self._enqueue(all_k if all_k is not None else k, shadow)
+        return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
+
+    def _enqueue(self, all_k, shadow):
+        """_update_memory + _update_pointer (reference :97-99), the bf16 mirror of an fp32 queue written by the same launch"""
         if shadow is not None:
             # fp32 `memory` and its bf16 mirror in ONE launch (same rows, rounded to bf16: the mirror stays exact)
             with torch.no_grad():
@@ -129,7 +133,17 @@ class MoCo(BaseMoCo):
         else:
             self._update_memory(all_k, self.memory)
         self._update_pointer(all_k.size(0))
-        return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
+
+    def forward_fused_into(self, q, k, all_k, qpack_buf, out):
+        """forward_fused without autograd, results into caller-owned static buffers (`out`: ops.K2Buffers) -- the form a step
+        replayed from HIP graphs calls between its forward and its backward graph (helper/step_graph.py; the autograd side
+        is ops.StaticK2Loss).  Same kernels, same order: one pass over the pre-enqueue queue, then the enqueue; the pointer
+        stays the host integer."""
+        shadow = None
+        if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
+            shadow = self._bf16_shadow()
+        ops.infonce_fused_into(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack_buf, out)
+        self._enqueue(all_k if all_k is not None else k, shadow)
 
 
 class MoCoAtt(BaseMoCo):

@@ -38,27 +38,206 @@ def _same_arch(a, b):
     return len(pa) == len(pb) and all(x.shape == y.shape for x, y in zip(pa, pb))
 
 
+class MomaStep:
+    """One training step of the moma / kd branch, cut where HIP graphs can be cut (helper/step_graph.py):
+
+        student_forward   the student's forward                                                    -- capturable, main stream
+        teacher_side      teacher forward #1, EMA (K4), Shuffle-BN key encoding, key-side attention (K1)
+                                                                                                   -- capturable, side stream
+        losses_and_query  CE + KL, embed_s, atts_q (K1; leaves q packed for K2), the student's top-1 -- capturable, after the join
+        kd_term           K2 + K3 (+ the host pointer): contrast.forward_fused (autograd) or, between graph replays,
+                          contrast.forward_fused_into (static buffers)                              -- always eager
+        backward_part     weighted sum, backward                                                    -- capturable
+
+    `run_eager` is these in sequence -- the loop body of the reference (helper/loops_moma.py:256-361) in its order."""
+
+    def __init__(self, module_list, criterion_list, trainer, contrast, optimizer, opt, dev):
+        self.criterion_cls, self.criterion_div, self.criterion_kd = criterion_list[0], criterion_list[1], criterion_list[2]
+        self.model_s, self.model_t = module_list[0], module_list[-1]
+        self.trainer, self.contrast, self.optimizer, self.opt, self.dev = trainer, contrast, optimizer, opt, dev
+        self.amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(getattr(opt, "amp", None))
+        self.scaler = getattr(opt, "_grad_scaler", None)
+        self.fused = getattr(opt, "moma_fused", True)
+        self.mocoatt = getattr(opt, "mem", "MoCo") == "MoCoAtt"
+        self.attn_in_shuffle = (opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix")
+                                and not self.mocoatt)
+        self.ema_ok = None
+        self.overlap = (getattr(opt, "overlap_teacher", False) and opt.distill == "moma" and dev.type == "cuda"
+                        and getattr(opt, "shuffle_bn", "per_rank") == "per_rank")
+
+    def autocast(self):
+        return torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None)
+
+    def graphable(self):
+        """What helper/step_graph.py captures: the bench / run-script configuration (--distill moma, one-pass K2, --attn self,
+        MoCo memory, per-rank Shuffle-BN, no GradScaler).  Everything else keeps the eager loop."""
+        o = self.opt
+        return (self.dev.type == "cuda" and o.distill == "moma" and self.fused and not self.mocoatt and not self.attn_in_shuffle
+                and getattr(o, "attn", "self") == "self" and self.scaler is None and hasattr(self.contrast, "forward_fused_into")
+                and getattr(o, "shuffle_bn", "per_rank") == "per_rank")
+
+    def teacher_side(self, images, teacher):
+        """teacher forward #1 (:270-272), then the moma branch's no-grad part (:309-320, :327-329)."""
+        opt, trainer, criterion_kd, model_t = self.opt, self.trainer, self.criterion_kd, self.model_t
+        with self.autocast(), torch.no_grad():
+            _, lt = teacher(images, is_feat=True)
+        if opt.distill != "moma":
+            return lt.float(), None, None
+        student = _unwrap(self.model_s)
+        if self.ema_ok is None:
+            self.ema_ok = _same_arch(student, model_t)
+            if not self.ema_ok and getattr(opt, "rank", 0) == 0:
+                # the reference raises half-way through the zip; defined behaviour here:
+                print("[moma] student/teacher architectures differ: teacher stays frozen (no EMA)")
+        if self.ema_ok:
+            trainer.momentum_update(student, model_t, opt.alpha)                     # K4 (:309)
+            if opt.head == "mlp":
+                criterion_kd.embed_t.eval()
+                if _same_arch(criterion_kd.embed_s, criterion_kd.embed_t):
+                    trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
+        model_t.apply(_set_bn_train)                                                  # (:314-318)
+        if self.attn_in_shuffle:         # key encoding + attention need the student's query: done on the main stream below
+            return lt.float(), None, None
+        with self.autocast():
+            kk, akk = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
+        kk, akk = kk.float(), akk.float()
+        if opt.attn == "self" and not self.mocoatt:                                   # K1, key side (:327-329)
+            with torch.no_grad():           # one group of launches for the two key-side modules
+                kk, akk = criterion_kd.atts_k.forward_group([criterion_kd.atts_k, criterion_kd.atts_queue], [kk, akk])
+        return lt.float(), kk, akk
+
+    def side_stream(self):
+        """the second HIP stream of the step (opt.overlap_teacher), None when the teacher side runs on the main stream"""
+        if not self.overlap:
+            return None
+        side = getattr(self.trainer, "_side_stream", None)
+        if side is None:
+            side = self.trainer._side_stream = torch.cuda.Stream(device=self.dev)
+        return side
+
+    def student_forward(self, images, student=None):
+        """(:268) -> (feat_s, logit_s)"""
+        student = self.model_s if student is None else student
+        with self.autocast():
+            return student(images, is_feat=True)
+
+    def losses_and_query(self, feat_s, logit_s, logit_t, k, all_k, images, labels, teacher, qpack=None, prefetch=True):
+        """CE + KL (:278-279), embed_s (:323-324), the query side of K1 (:326), the student's top-1
+        -> dict(loss_cls, loss_div, f_s, k, all_k, acc, qp)"""
+        opt, trainer, criterion_kd, contrast = self.opt, self.trainer, self.criterion_kd, self.contrast
+        logit_s = logit_s.float()
+        out = {"loss_cls": self.criterion_cls(logit_s, labels), "loss_div": self.criterion_div(logit_s, logit_t), "qp": None}
+        f_s = None
+        if opt.distill == "moma":
+            with self.autocast():
+                f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
+            f_s = f_s.float()
+            if self.attn_in_shuffle:
+                # attn in {self_mix, self_nomix}: Shuffle-BN key encoding with the attention applied before the un-shuffle,
+                # over [q ; k] or per side (reference learning/contrast_trainer.py:135-187; train_student_moma.py:345-352
+                # registers these modules as trainable -- the reference loop never reaches the call, SURVEY Q10)
+                with self.autocast():
+                    f_s, k, all_k = trainer._shuffle_bn_attn(images, teacher, criterion_kd.embed_t, criterion_kd, f_s)
+                f_s, k, all_k = f_s.float(), k.float(), all_k.float()
+            elif opt.attn == "self" and not self.mocoatt:                                 # K1, query side (:326)
+                if prefetch:
+                    self.prefetch_queue()
+                # atts_q's proj epilogue also leaves q in the packed bf16 layout K2 loads it in (no pre-pack launch in K2)
+                if qpack is None and self.fused and hasattr(contrast, "qpack"):
+                    qpack = contrast.qpack(f_s.shape[0], f_s.shape[1], f_s.device)
+                f_s = criterion_kd.atts_q(f_s, qpack=qpack)
+                out["qp"] = qpack
+        out.update(f_s=f_s, k=k, all_k=all_k, acc=accuracy(logit_s, labels, topk=(1,))[0].squeeze(0))
+        return out
+
+    def prefetch_queue(self):
+        """the queue was last read a whole step ago: sweep it into the Infinity Cache on the side stream while the
+        (launch-latency-bound) attention module runs on the main one; K2 then streams it at cache latency"""
+        if self.overlap and self.fused and getattr(self.opt, "prefetch_queue", True) and hasattr(self.contrast, "prefetch"):
+            self.contrast.prefetch(stream=self.side_stream())
+
+    def forward_part(self, images, labels, teacher):
+        """-> dict(loss_cls, loss_div, f_s, k, all_k, acc, qp).  opt.overlap_teacher: everything on the teacher / key side of the
+        step (all no-grad) is queued on a second HIP stream and runs concurrently with the student forward; the streams join
+        before the losses.  Same operations in the same order per stream as the sequential loop -- the two chains do not
+        depend on each other until the loss."""
+        main_stream = torch.cuda.current_stream() if self.dev.type == "cuda" else None
+        side = self.side_stream()
+        if side is not None:
+            side.wait_stream(main_stream)                     # last step's optimizer, this step's images
+            with torch.cuda.stream(side):
+                logit_t, k, all_k = self.teacher_side(images, teacher)
+        feat_s, logit_s = self.student_forward(images)
+        if side is not None:
+            main_stream.wait_stream(side)
+            for t in (logit_t, k, all_k):
+                if t is not None:
+                    t.record_stream(main_stream)
+        else:
+            logit_t, k, all_k = self.teacher_side(images, teacher)
+        return self.losses_and_query(feat_s, logit_s, logit_t, k, all_k, images, labels, teacher)
+
+    def kd_term(self, fw):
+        """K2 + K3 through autograd (the eager step): -> loss_kd"""
+        opt, trainer, contrast, criterion_kd = self.opt, self.trainer, self.contrast, self.criterion_kd
+        if opt.distill == "kd":
+            return 0
+        if opt.distill != "moma":
+            raise NotImplementedError(opt.distill)
+        f_s, k, all_k, qp = fw["f_s"], fw["k"], fw["all_k"], fw["qp"]
+        if self.mocoatt:
+            # --mem MoCoAtt: the memory applies the teacher-student cross-attention variant itself
+            # (reference MoMA/mem_moco.py:111-161); materialised logits -> CrossEntropy as in :331-335
+            if opt.attn == "dual2":
+                raise NotImplementedError("attn='dual2' yields positive logits only ([B]); the reference's CrossEntropy "
+                                          "over them is undefined (MoMA/mem_moco.py:51-66,148-149)")
+            criterion = nn.CrossEntropyLoss()
+            output = contrast(q=f_s, k=k, all_k=all_k, attn=opt.attn, criterion_kd=criterion_kd)
+            c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
+            return c_losses[0]
+        if self.fused:                                                                    # K2 + K3
+            loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k, **({"qpack": qp} if qp is not None else {}))
+            return loss_kd
+        criterion = nn.CrossEntropyLoss()                                                 # reference sequence (:331-335)
+        output = contrast(q=f_s, k=k, all_k=all_k)
+        c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
+        return c_losses[0]
+
+    def backward_part(self, fw, loss_kd):
+        """weighted sum (:350) and backward (:359-360); gradients start from None (zero_grad(set_to_none=True), the reference's call)"""
+        opt = self.opt
+        loss = opt.cls * fw["loss_cls"] + opt.div * fw["loss_div"] + opt.beta * loss_kd
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        return loss
+
+    def run_eager(self, images, labels, teacher):
+        fw = self.forward_part(images, labels, teacher)
+        loss_kd = self.kd_term(fw)
+        loss = self.backward_part(fw, loss_kd)
+        return loss.detach(), (loss_kd.detach() if torch.is_tensor(loss_kd) else loss_kd), fw["acc"]
+
+
 def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer, contrast, optimizer, opt):
     """one epoch distillation; returns (top1.avg, losses.avg) like the reference."""
     for module in module_list:
         module.train()
     module_list[-1].eval()                      # teacher in eval for its first forward (:227)
 
-    criterion_cls, criterion_div, criterion_kd = criterion_list[0], criterion_list[1], criterion_list[2]
+    criterion_kd = criterion_list[2]
     model_s, model_t = module_list[0], module_list[-1]
 
     batch_time, losses, top1 = AverageMeter(), AverageMeter(), AverageMeter()
     n_batch = len(train_loader)
-    amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(getattr(opt, "amp", None))
     scaler = getattr(opt, "_grad_scaler", None)
-    fused = getattr(opt, "moma_fused", True)
     dev = getattr(opt, "device", None)
     if dev is None:
         dev = torch.device("cuda", opt.gpu if (opt.gpu is not None and opt.multiprocessing_distributed) else 0) \
             if torch.cuda.is_available() else torch.device("cpu")
-    ema_ok = None
-    mocoatt = getattr(opt, "mem", "MoCo") == "MoCoAtt"
-    attn_in_shuffle = opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix") and not mocoatt
+    step = MomaStep(module_list, criterion_list, trainer, contrast, optimizer, opt, dev)
     single_rank = bool(getattr(trainer, "grad_sync_single_rank", False))
     sync_criterion = opt.distill == "moma" and (getattr(opt, "world_size", 1) > 1 or single_rank)
     flat_dp = isinstance(model_s, FlatDataParallel)
@@ -76,12 +255,29 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
     # the teacher's two no-grad forwards per step are replayed from a HIP graph after a few eager calls
     # (opt.graph_teacher, default on for GPU runs; see helper/graphs.py); everything else uses `model_t` itself
     teacher = model_t
+    holder = trainer if trainer is not None else opt          # (--distill kd runs without a ContrastTrainer)
     if getattr(opt, "graph_teacher", True) and dev.type == "cuda":
-        holder = trainer if trainer is not None else opt          # (--distill kd runs without a ContrastTrainer)
         teacher = getattr(holder, "_graphed_teacher", None)
         if teacher is None or teacher.module is not model_t:
             from .graphs import GraphedInference
             teacher = holder._graphed_teacher = GraphedInference(model_t)
+    # the step itself -- student forward + backward, the teacher side, K1, K4 -- replayed from two HIP graphs with K2 / K3 called
+    # between them (opt.graph_student, default on where MomaStep.graphable(); helper/step_graph.py).  Stock DDP's reducer lives
+    # in autograd hooks and cannot be captured: the flat wrap (one collective per step, outside the graphs) or a single rank.
+    runner = None
+    if getattr(opt, "graph_student", True) and step.graphable() and (flat_dp or not hasattr(model_s, "module")):
+        from .step_graph import StepGraphs
+        runner = getattr(holder, "_step_graphs", None)
+        if runner is None or not runner.same_objects(step):
+            runner = holder._step_graphs = StepGraphs()
+        runner.bind(step)
+    elif (getattr(opt, "graph_student", True) and step.graphable() and epoch <= 1 and getattr(opt, "rank", 0) == 0
+          and getattr(opt, "graph_student_notice", True)):
+        print("[moma] --dp ddp: the stock reducer works from autograd hooks, the student step stays eager (no HIP graph)")
+    if (epoch <= 1 and getattr(opt, "overlap_teacher", False) and not step.overlap and dev.type == "cuda"
+            and opt.distill == "moma" and getattr(opt, "rank", 0) == 0):
+        print("[moma] --shuffle_bn gather: the teacher side stays on the main stream (its collectives are ordered "
+              "with the DDP all-reduce there); overlap_teacher is off in this mode")
     trace = getattr(opt, "trace", None)
     step_events = getattr(opt, "step_events", None)     # optional (bench.py): (host time, HIP event) at the end of every step
 
@@ -93,129 +289,19 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         if getattr(opt, "channels_last", False):
             images = images.contiguous(memory_format=torch.channels_last)
 
-        # =================== forward =====================
-        # opt.overlap_teacher: everything on the teacher / key side of the step (teacher forward #1, EMA, Shuffle-BN key
-        # encoding, key-side attention: all no-grad) is queued on a second HIP stream and runs concurrently with the student
-        # forward; the streams join before the losses.  Same operations in the same order per stream as the sequential
-        # loop -- the two chains do not depend on each other until the loss.
-        overlap = (getattr(opt, "overlap_teacher", False) and opt.distill == "moma" and dev.type == "cuda"
-                   and getattr(opt, "shuffle_bn", "per_rank") == "per_rank")
-        if (idx == 0 and epoch <= 1 and getattr(opt, "overlap_teacher", False) and not overlap and dev.type == "cuda"
-                and opt.distill == "moma" and getattr(opt, "rank", 0) == 0):
-            print("[moma] --shuffle_bn gather: the teacher side stays on the main stream (its collectives are ordered "
-                  "with the DDP all-reduce there); overlap_teacher is off in this mode")
-        main_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
-
-        def teacher_side():
-            """teacher forward #1 (:270-272), then the moma branch's no-grad part (:309-320, :327-329)."""
-            nonlocal ema_ok
-            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None), torch.no_grad():
-                _, lt = teacher(images, is_feat=True)
-            if opt.distill != "moma":
-                return lt.float(), None, None
-            student = _unwrap(model_s)
-            if ema_ok is None:
-                ema_ok = _same_arch(student, model_t)
-                if not ema_ok and getattr(opt, "rank", 0) == 0:
-                    # the reference raises half-way through the zip; defined behaviour here:
-                    print("[moma] student/teacher architectures differ: teacher stays frozen (no EMA)")
-            if ema_ok:
-                trainer.momentum_update(student, model_t, opt.alpha)                     # K4 (:309)
-                if opt.head == "mlp":
-                    criterion_kd.embed_t.eval()
-                    if _same_arch(criterion_kd.embed_s, criterion_kd.embed_t):
-                        trainer.momentum_update(criterion_kd.embed_s, criterion_kd.embed_t, opt.alpha)
-            model_t.apply(_set_bn_train)                                                  # (:314-318)
-            if attn_in_shuffle:         # key encoding + attention need the student's query: done on the main stream below
-                return lt.float(), None, None
-            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                kk, akk = trainer._shuffle_bn(images, teacher, model_ema_head=criterion_kd.embed_t)   # (:320)
-            kk, akk = kk.float(), akk.float()
-            if opt.attn == "self" and not mocoatt:                                        # K1, key side (:327-329)
-                with torch.no_grad():           # one group of launches for the two key-side modules
-                    kk, akk = criterion_kd.atts_k.forward_group([criterion_kd.atts_k, criterion_kd.atts_queue], [kk, akk])
-            return lt.float(), kk, akk
-
-        if overlap:
-            side = getattr(trainer, "_side_stream", None)
-            if side is None:
-                side = trainer._side_stream = torch.cuda.Stream(device=dev)
-            side.wait_stream(main_stream)                     # last step's optimizer, this step's images
-            with torch.cuda.stream(side):
-                logit_t, k, all_k = teacher_side()
-        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-            feat_s, logit_s = model_s(images, is_feat=True)
-        if overlap:
-            main_stream.wait_stream(side)
-            for t in (logit_t, k, all_k):
-                if t is not None:
-                    t.record_stream(main_stream)
-        else:
-            logit_t, k, all_k = teacher_side()
-        logit_s = logit_s.float()
-
-        loss_cls = criterion_cls(logit_s, labels)
-        loss_div = criterion_div(logit_s, logit_t)
-        qp = None
-
-        if opt.distill == "kd":
-            loss_kd = 0
-        elif opt.distill == "moma":
-            with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                f_s = criterion_kd.embed_s(feat_s[-1])                                    # (:323-324)
-            f_s = f_s.float()
-            if attn_in_shuffle:
-                # attn in {self_mix, self_nomix}: Shuffle-BN key encoding with the attention applied before the un-shuffle,
-                # over [q ; k] or per side (reference learning/contrast_trainer.py:135-187; train_student_moma.py:345-352
-                # registers these modules as trainable -- the reference loop never reaches the call, SURVEY Q10)
-                with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
-                    f_s, k, all_k = trainer._shuffle_bn_attn(images, teacher, criterion_kd.embed_t, criterion_kd, f_s)
-                f_s, k, all_k = f_s.float(), k.float(), all_k.float()
-            elif opt.attn == "self" and not mocoatt:                                      # K1, query side (:326)
-                if overlap and fused and getattr(opt, "prefetch_queue", True) and hasattr(contrast, "prefetch"):
-                    # the queue was last read a whole step ago: sweep it into the Infinity Cache on the side stream while the
-                    # (launch-latency-bound) attention module runs here; K2 then streams it at cache latency
-                    contrast.prefetch(stream=side)
-                # atts_q's proj epilogue also leaves q in the packed bf16 layout K2 loads it in (no pre-pack launch in K2)
-                qp = contrast.qpack(f_s.shape[0], f_s.shape[1], f_s.device) if (fused and hasattr(contrast, "qpack")) else None
-                f_s = criterion_kd.atts_q(f_s, qpack=qp)
-
-            if mocoatt:
-                # --mem MoCoAtt: the memory applies the teacher-student cross-attention variant itself
-                # (reference MoMA/mem_moco.py:111-161); materialised logits -> CrossEntropy as in :331-335
-                if opt.attn == "dual2":
-                    raise NotImplementedError("attn='dual2' yields positive logits only ([B]); the reference's CrossEntropy "
-                                              "over them is undefined (MoMA/mem_moco.py:51-66,148-149)")
-                criterion = nn.CrossEntropyLoss()
-                output = contrast(q=f_s, k=k, all_k=all_k, attn=opt.attn, criterion_kd=criterion_kd)
-                c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
-                loss_kd = c_losses[0]
-            elif fused:                                                                   # K2 + K3
-                loss_kd, _acc_kd = contrast.forward_fused(f_s, k, all_k, **({"qpack": qp} if qp is not None else {}))
-            else:                                                                         # reference sequence (:331-335)
-                criterion = nn.CrossEntropyLoss()
-                output = contrast(q=f_s, k=k, all_k=all_k)
-                c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1],
-                                                             criterion=criterion)
-                loss_kd = c_losses[0]
-        else:
-            raise NotImplementedError(opt.distill)
-
-        loss = opt.cls * loss_cls + opt.div * loss_div + opt.beta * loss_kd
-        losses.update(loss.detach(), images.size(0))
+        # =================== forward, KD term, backward =====================
+        res = runner.step(images, labels) if runner is not None else None      # None: this step is not (yet) served from graphs
+        if res is None:
+            res = step.run_eager(images, labels, teacher)
+        loss, loss_kd, acc = res
+        losses.update(loss, images.size(0))
         if trace is not None:           # optional per-step record (tests / benchmarking), device tensors
-            trace.append((loss.detach(), contrast.index if contrast is not None else None,
-                          loss_kd.detach() if torch.is_tensor(loss_kd) else loss_kd))
+            trace.append((loss, contrast.index if contrast is not None else None, loss_kd))
 
         # =================== metrics =====================
-        top1.update(accuracy(logit_s, labels, topk=(1,))[0].squeeze(0), images.size(0))
+        top1.update(acc, images.size(0))
 
-        # =================== backward =====================
-        optimizer.zero_grad(set_to_none=True)
-        if scaler is not None:
-            scaler.scale(loss).backward()
-        else:
-            loss.backward()
+        # =================== gradient exchange, optimizer =====================
         if flat_dp:
             n_red = model_s.allreduce_grads(flat_params, single_rank=single_rank)
             if trainer is not None and n_red:
@@ -233,7 +319,7 @@ def train_distill_moma(epoch, train_loader, module_list, criterion_list, trainer
         if step_events is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            step_events.append((time.perf_counter(), ev))
+            step_events.append((time.perf_counter(), ev, time.thread_time()))
 
         if idx % opt.print_freq == 0:
             print("Epoch: [{0}][{1}/{2}]\tGPU {3}\tTime: {bt:.3f}\tLoss {loss:.4f}\tAcc@1 {acc:.3f}".format(

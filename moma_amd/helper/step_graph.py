@@ -1,0 +1,264 @@
+"""The MoMA training step replayed from HIP graphs (the host out of the step).
+
+A step of the reference loop (helper/loops_moma.py:256-361) is ~2400 kernel launches; issued one by one through Python / ATen /
+MIOpen that is ~35 ms of host time against ~40 ms of GPU time at B = 256 -- host-bound at B <= 190, and the first thing eight
+ranks sharing one host run out of.  The step has fixed shapes and a fixed launch sequence, so after a few eager steps it is
+captured ONCE into four HIP graphs and replayed, on the same two streams and with the same joins as the eager loop:
+
+    side stream : g_teacher  teacher forward #1, K4 EMA, Shuffle-BN key encoding, K1 key side (all no-grad)
+    main stream : g_student  the student's forward                                 -- concurrent with g_teacher
+                  (join)     main waits for the side stream; the queue prefetch is launched on the side stream
+                  g_query    CE + KL, embed_s, K1 query side (leaves q packed for K2), the student's top-1
+                  eager      K2 (one pass over the queue, into static buffers) + K3 (enqueue): the ring pointer stays the HOST
+                             integer of the contract (a launch argument of a captured kernel is frozen, the pointer moves every
+                             step), and the measurement events bench.py puts on K2's dispatches keep working (an event recorded
+                             inside a capture is a graph node without a timestamp; external event nodes are refused by this
+                             runtime -- scripts/diag_graph_events.py)
+                  g_bwd      weighted loss, backward (K1 backward included); ops.StaticK2Loss is the autograd node that stands
+                             for the K2 call
+                  eager      the data-parallel gradient all-reduce (learning/ddp.py: ONE flat collective), optimizer.step()
+
+Why not ONE graph with the teacher side as a forked branch: measured (round 4, B = 256) a graph with the fork runs the step in
+43.5 ms against 40.1 ms eager and 42.0 ms for either without the second stream -- the runtime does not overlap the branches of
+one graph, it only adds their synchronisation.  Two graphs replayed on two streams overlap as the eager chains do.
+g_student / g_query / g_bwd share one memory pool (the backward consumes the activations the forward graphs saved), g_teacher has
+its own; each family is captured on a stream of its own (library workspaces are per stream: nothing eager ever runs on the
+capture streams) and replayed on the loop's main / side stream only.  What changes from step to step enters through static
+inputs: the batch (copied in), the Shuffle-BN permutation (drawn from the HOST generator exactly as the eager loop draws it --
+one per step -- and copied in through pinned memory: PermFeed), the weights (read in place; the attention weight packs are
+rebuilt inside the graphs), the queue (read in place by the eager K2).  Host-side state the captured Python would have advanced
+is advanced per replay: the BatchNorm batch counters, the `.grad` attributes (the graph's static gradient tensors are
+re-attached after every replay -- an eager step in between drops them with zero_grad(set_to_none=True)).
+
+A (shape, train / eval flags, queue storage) variant is captured after `warmup` eager steps (MIOpen / hipBLASLt have selected
+their kernels by then); the first step of every epoch (teacher still in eval mode, reference :227) is a variant of its own that
+is seen once per epoch and stays eager, as does a ragged last batch.  Capture uses CUDAGraph.capture_begin / capture_end
+directly: `torch.cuda.graph` empties the caching allocator's pool on entry, and the next EAGER step would pay for it with
+hundreds of milliseconds of hipMalloc (seen in round 3 with the teacher graphs).
+"""
+from __future__ import annotations
+
+import gc
+import os
+
+import torch
+
+from .. import ops
+
+
+class PermFeed:
+    """The Shuffle-BN permutation as a static graph input: `push()` draws the step's permutation from the host generator
+    (torch.randperm -- the reference's stream, learning/contrast_trainer.py:108) into a ring of pinned buffers and queues the
+    copy into the device tensor the captured gather reads."""
+
+    SLOTS = 4
+
+    def __init__(self, n: int, device):
+        self.n = n
+        self.static = torch.zeros(n, dtype=torch.int64, device=device)
+        self.static.copy_(torch.arange(n))
+        self.pinned = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(self.SLOTS)]
+        self.done = [None] * self.SLOTS
+        self.i = 0
+
+    def take(self, n, device):
+        if n != self.n or device != self.static.device:
+            raise RuntimeError(f"captured step asked for a permutation of {n} on {device}, feed holds {self.n} on {self.static.device}")
+        return self.static
+
+    def push(self):
+        j = self.i % self.SLOTS
+        self.i += 1
+        if self.done[j] is not None:
+            self.done[j].synchronize()                   # (four steps back: long done)
+        torch.randperm(self.n, out=self.pinned[j])
+        self.static.copy_(self.pinned[j], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[j] = ev
+
+
+class _Captured:
+    pass
+
+
+class StepGraphs:
+    """Serves MomaStep steps from captured graphs where it can; `step()` returns None when the caller has to run the step
+    eagerly (variant not captured yet / not capturable)."""
+
+    def __init__(self, warmup: int = 3, max_graphs: int = 2):
+        self.warmup, self.max_graphs = warmup, max_graphs
+        self.enabled = os.environ.get("MOMA_GRAPH_STUDENT", "1") == "1"
+        self.graphs, self.seen = {}, {}
+        self.st = None
+        self.capture_stream = None
+        self.replays = 0
+
+    # ---- binding to the objects of a training run -------------------------------------------------------------------------
+    def same_objects(self, st) -> bool:
+        o = self.st
+        return o is not None and o.model_s is st.model_s and o.model_t is st.model_t and o.criterion_kd is st.criterion_kd \
+            and o.contrast is st.contrast and o.optimizer is st.optimizer and o.trainer is st.trainer
+
+    def bind(self, st) -> None:
+        """`st`: the epoch's MomaStep (a new object per epoch over the same models).  The captured graphs stay valid -- they
+        hold device addresses, not the Python object."""
+        self.st = st
+        from .loops_moma import _unwrap
+        self._mods = list(_unwrap(st.model_s).modules()) + list(st.model_t.modules()) + list(st.criterion_kd.modules())
+        self._bn = [m for m in self._mods if hasattr(m, "_nbt_pending")]
+
+    def _streamed_queue(self):
+        """the tensor K2 streams: `memory`, or the bf16 mirror of an fp32 `memory` under the bf16 policy (made here if absent)"""
+        c = self.st.contrast
+        if c.memory.dtype == torch.float32 and ops.prec_code(c.precision) == ops.PREC_BF16:
+            return c._bf16_shadow()
+        return c.memory
+
+    def _key(self, images, labels):
+        st = self.st
+        # (queue storage is part of the key: the captured prefetch-free graphs do not read it, but the static K2 buffers are sized
+        #  for it, and a replaced `memory` -- .cuda(), load_state_dict -- must not meet buffers of another shape)
+        return (tuple(images.shape), images.dtype, images.is_contiguous(), tuple(labels.shape), labels.dtype,
+                hash(tuple(m.training for m in self._mods)), st.contrast.memory.data_ptr(), self._streamed_queue().data_ptr(),
+                st.contrast.T, st.amp_dtype, st.overlap, float(st.opt.cls), float(st.opt.div), float(st.opt.beta),
+                float(st.opt.alpha))
+
+    # ---- one step ---------------------------------------------------------------------------------------------------------
+    def step(self, images, labels):
+        if not self.enabled or not images.is_cuda:
+            return None
+        key = self._key(images, labels)
+        cap = self.graphs.get(key)
+        if cap is None:
+            n = self.seen.get(key, 0) + 1
+            if len(self.seen) < 64 or key in self.seen:
+                self.seen[key] = n
+            if n <= self.warmup or len(self.graphs) >= self.max_graphs:
+                return None
+            cap = self._capture(key, images, labels)
+            if cap is None:
+                return None
+        return self._replay(cap, images, labels)
+
+    def _replay(self, cap, images, labels):
+        st = self.st
+        main = torch.cuda.current_stream(images.device)
+        cap.images.copy_(images, non_blocking=True)
+        cap.labels.copy_(labels, non_blocking=True)
+        cap.perm.push()
+        wrap = st.model_s
+        if hasattr(wrap, "flat_buffer_broadcast"):
+            wrap.flat_buffer_broadcast()                   # the wrap's per-forward collective: outside the graphs
+        side = st.side_stream()
+        if side is not None:
+            side.wait_stream(main)                         # last step's optimizer, this step's inputs
+            with torch.cuda.stream(side):
+                cap.g_teacher.replay()
+            cap.g_student.replay()
+            main.wait_stream(side)
+            st.prefetch_queue()                            # (on the side stream, under the attention launches of g_query)
+        else:
+            cap.g_student.replay()
+            cap.g_teacher.replay()
+        cap.g_query.replay()
+        fw = cap.fw
+        st.contrast.forward_fused_into(fw["f_s"], fw["k"], fw["all_k"], None if cap.qpack is None else cap.qpack.buf, cap.k2)
+        cap.g_bwd.replay()
+        for m, dn in cap.bn_delta:
+            m._nbt_pending += dn
+        for p, g in cap.grads:
+            p.grad = g
+        self.replays += 1
+        # (static outputs: the next replay overwrites them -- what is handed out is a copy)
+        return cap.loss.clone(), cap.loss_kd.clone(), fw["acc"].clone()
+
+    # ---- capture ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _record(graph, stream, fn, pool=None):
+        """run fn() on `stream` under a capture into `graph` (CUDAGraph.capture_begin / capture_end: no empty_cache)"""
+        with torch.cuda.stream(stream):
+            if pool is None:
+                graph.capture_begin(capture_error_mode="thread_local")
+            else:
+                graph.capture_begin(pool=pool, capture_error_mode="thread_local")
+            try:
+                return fn()
+            finally:
+                graph.capture_end()
+
+    def _capture(self, key, images, labels):
+        st = self.st
+        from .loops_moma import _unwrap
+        dev = images.device
+        trainer, contrast, kd = st.trainer, st.contrast, st.criterion_kd
+        cap = _Captured()
+        bn_before = [(m, m._nbt_pending) for m in self._bn]
+        try:
+            B = images.shape[0]
+            d, K = contrast.memory.shape[1], contrast.memory.shape[0]
+            cap.images, cap.labels = images.clone(), labels.clone()
+            cap.perm = PermFeed(B, dev)
+            cap.qpack = None
+            if ops.prec_code(contrast.precision) == ops.PREC_BF16:
+                cap.qpack = ops.QPack().prepare(B, d, contrast.T, dev)        # this graph's own packed-q image (None: K2 packs)
+            cap.k2 = ops.K2Buffers(B, d, K, self._streamed_queue().dtype, contrast.precision, dev)
+            # the graphs own what they read besides parameters and buffers: weight packs of the attention modules are rebuilt
+            # inside the graphs (into their pools) on every replay
+            for m in kd.modules():
+                if hasattr(m, "invalidate_pack"):
+                    m.invalidate_pack()
+            st.optimizer.zero_grad(set_to_none=True)                          # the captured backward CREATES the gradients
+            if self.capture_stream is None:
+                self.capture_stream = torch.cuda.Stream(device=dev)
+                self.capture_stream_side = torch.cuda.Stream(device=dev)
+            gc.collect()
+            torch.clear_autocast_cache()
+            main = torch.cuda.current_stream(dev)
+            cs, cs_side = self.capture_stream, self.capture_stream_side
+            cs.wait_stream(main)
+            cs_side.wait_stream(main)
+            trainer._perm_feed = cap.perm
+            student = _unwrap(st.model_s)
+            cap.g_student, cap.g_teacher = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            cap.g_query, cap.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # (a capture executes nothing: the order of the captures only has to respect the data flow of the Python objects)
+            feat_s, logit_s = self._record(cap.g_student, cs, lambda: st.student_forward(cap.images, student))
+            torch.clear_autocast_cache()
+            logit_t, k, all_k = self._record(cap.g_teacher, cs_side, lambda: st.teacher_side(cap.images, st.model_t))
+            torch.clear_autocast_cache()
+            pool = cap.g_student.pool()
+            fw = self._record(cap.g_query, cs, lambda: st.losses_and_query(feat_s, logit_s, logit_t, k, all_k, cap.images, cap.labels,
+                                                                          st.model_t, qpack=cap.qpack, prefetch=False), pool)
+            del feat_s, logit_s
+
+            def bwd():
+                loss_kd = ops.StaticK2Loss.apply(fw["f_s"], cap.k2.loss_rows, cap.k2.dq).mean()
+                loss = st.backward_part(fw, loss_kd)
+                return loss.detach(), loss_kd.detach()
+            cap.loss, cap.loss_kd = self._record(cap.g_bwd, cs, bwd, pool)
+            main.wait_stream(cs)
+            main.wait_stream(cs_side)
+            torch.clear_autocast_cache()
+            cap.fw = {k_: (v.detach() if torch.is_tensor(v) else v) for k_, v in fw.items()}
+            cap.teacher_out = (logit_t, k, all_k)
+            params = [p for g in st.optimizer.param_groups for p in g["params"]]
+            cap.grads = [(p, p.grad) for p in params]
+            # the capture ran the Python side once WITHOUT executing anything: undo its host-side counting, remember the deltas
+            cap.bn_delta = [(m, m._nbt_pending - before) for m, before in bn_before if m._nbt_pending != before]
+            # device tables the captured K4 launches read (rebuilt -- and the old one freed -- only if a parameter moves)
+            cap.keepalive = list(type(trainer)._ema_tables.values())
+            self.graphs[key] = cap
+            if getattr(st.opt, "rank", 0) == 0:
+                print(f"[moma] step captured into HIP graphs (batch {B}, variant {len(self.graphs)}): student forward || teacher "
+                      f"side | losses + query | K2 / K3 eager | backward")
+            return cap
+        except Exception as e:                                 # pragma: no cover - depends on the runtime
+            print(f"[moma] HIP-graph capture of the training step failed ({type(e).__name__}: {e}); staying eager")
+            self.enabled = False
+            st.optimizer.zero_grad(set_to_none=True)
+            return None
+        finally:
+            trainer._perm_feed = None
+            for m, before in bn_before:
+                m._nbt_pending = before

@@ -89,10 +89,15 @@ class ContrastTrainer(BaseTrainer):
         k = all_k[reverse_ids]
         return k, all_k
 
-    @staticmethod
-    def _host_randperm(n, device):
+    _perm_feed = None      # set by helper/step_graph.py while a step is captured: the permutation's static device tensor
+
+    def _host_randperm(self, n, device):
         """torch.randperm from the HOST generator (the reference's stream: seeded runs draw identical permutations), moved
-        through pinned memory without blocking -- a pageable H2D copy is a host-device sync every step."""
+        through pinned memory without blocking -- a pageable H2D copy is a host-device sync every step.  While a step is being
+        captured into a HIP graph the permutation is the graph's static input (drawn from the same generator, one per step,
+        and copied in before every replay: step_graph.PermFeed)."""
+        if self._perm_feed is not None:
+            return self._perm_feed.take(n, device)
         if device.type != "cuda":
             return torch.randperm(n).to(device)
         return torch.randperm(n, pin_memory=True).to(device, non_blocking=True)

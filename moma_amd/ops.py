@@ -87,7 +87,10 @@ class _NullCtx:
 
 
 def _timed(name):
-    return _EVENT_RECORDER(name) if _EVENT_RECORDER is not None else _NullCtx()
+    # (no events inside a stream capture: an event recorded there becomes a graph node and carries no timestamp)
+    if _EVENT_RECORDER is None or torch.cuda.is_current_stream_capturing():
+        return _NullCtx()
+    return _EVENT_RECORDER(name)
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # the handle without building a Stream object
@@ -265,6 +268,62 @@ class QPack:
         return self.buf is not None and self.src == (q.data_ptr(), q._version, tuple(q.shape), float(T))
 
 
+class K2Buffers:
+    """Caller-owned outputs + workspace of one moma_infonce_fused call at a fixed shape: what a step replayed from HIP graphs
+    (helper/step_graph.py) hands to K2 every step -- the graphs on either side of the call read / write these addresses."""
+
+    def __init__(self, B: int, d: int, K: int, queue_dtype, prec, device):
+        lib = _lib.load()
+        self.shape = (B, d, K)
+        self.loss_rows = torch.empty(B, device=device, dtype=torch.float32)
+        self.lse = torch.empty(B, device=device, dtype=torch.float32)
+        self.top1 = torch.empty(B, device=device, dtype=torch.int32)
+        self.dq = torch.empty(B, d, device=device, dtype=torch.float32)
+        qd = DT_BF16 if queue_dtype == torch.bfloat16 else DT_F32
+        self.ws = torch.empty(max(lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec_code(prec)), 16), device=device,
+                              dtype=torch.uint8)
+
+
+def _infonce_fused_launch(q, k, queue, T, prec, qpack_buf, loss_rows, lse, top1, dq, ws):
+    lib = _lib.load()
+    B, d = q.shape
+    K = queue.shape[0]
+    ev0, ev1, ev2 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None, None)
+    with _timed("moma_infonce_fused"):
+        check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack_buf), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
+                                       _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), _qdtype(queue), prec,
+                                       _stream(), C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
+              "moma_infonce_fused")
+
+
+def infonce_fused_into(q, k, queue, T: float, prec, qpack_buf, out: K2Buffers) -> None:
+    """moma_infonce_fused into caller-owned buffers, no autograd: loss_rows / lse / top1 / dq (= d sum(loss_rows) / dq) land in
+    `out`.  qpack_buf: the packed image of q its producer wrote (or None: K2 packs q itself)."""
+    q = q.detach(); k = k.detach()
+    _check_qk(_dev(q, "q"), _dev(k, "k"), queue)
+    if (q.shape[0], q.shape[1], queue.shape[0]) != out.shape:
+        raise ValueError(f"K2Buffers were made for (B, d, K) = {out.shape}, got {(q.shape[0], q.shape[1], queue.shape[0])}")
+    pc = prec_code(prec)
+    if qpack_buf is not None and not (queue.dtype == torch.bfloat16 and pc == PREC_BF16):
+        qpack_buf = None
+    _infonce_fused_launch(q, k, queue, float(T), pc, qpack_buf, out.loss_rows, out.lse, out.top1, out.dq, out.ws)
+
+
+class StaticK2Loss(torch.autograd.Function):
+    """The autograd node that stands for a K2 call made OUTSIDE the captured graphs: forward hands out the loss rows K2 left in
+    its static buffer, backward is K2's own (dq * upstream, as _InfoNCEFused.backward)."""
+
+    @staticmethod
+    def forward(ctx, q, loss_rows_buf, dq_buf):
+        ctx.save_for_backward(dq_buf)
+        return loss_rows_buf.view_as(loss_rows_buf)
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (dq,) = ctx.saved_tensors
+        return dq * g_loss.unsqueeze(1), None, None
+
+
 class _InfoNCEFused(torch.autograd.Function):
     """One pass over the queue: per-row CE(label 0) loss, lse, top-1 flag and d(sum loss)/dq."""
 
@@ -281,15 +340,9 @@ class _InfoNCEFused(torch.autograd.Function):
         lse = torch.empty(B, device=dev, dtype=torch.float32)
         top1 = torch.empty(B, device=dev, dtype=torch.int32)
         dq = torch.empty(B, d, device=dev, dtype=torch.float32) if need_grad else None
-        qd = _qdtype(queue)
-        ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, qd, prec)
+        ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, _qdtype(queue), prec)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        ev0, ev1, ev2 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None, None)
-        with _timed("moma_infonce_fused"):
-            check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
-                                           _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), qd, prec,
-                                           _stream(), C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
-                  "moma_infonce_fused")
+        _infonce_fused_launch(q, k, queue, T, prec, qpack, loss_rows, lse, top1, dq, ws)
         if need_grad:
             ctx.save_for_backward(dq)
         ctx.mark_non_differentiable(lse, top1)

@@ -10,7 +10,7 @@ and launch lines carry over.  What differs:
   * one process per GPU either through torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) or, as in the
     reference, `--multiprocessing-distributed` + mp.spawn; the backend string 'nccl' is RCCL on ROCm;
   * new optional flags: --moma_prec, --queue_dtype, --amp, --channels_last, --shuffle_bn, --no_fused,
-    --steps_per_epoch, --num_heads, --dp (student wrap at world size > 1: flat = one gradient all-reduce per step, the
+    --steps_per_epoch, --num_heads, --no_graph_teacher, --no_graph_student, --dp (student wrap at world size > 1: flat = one gradient all-reduce per step, the
     default; ddp = stock DistributedDataParallel as in the reference).
 """
 from __future__ import print_function
@@ -119,6 +119,9 @@ def build_parser():
                    help="run the teacher / key side of the step on the main stream instead of a second HIP stream")
     p.add_argument("--no_graph_teacher", dest="graph_teacher", action="store_false",
                    help="run the teacher's two no-grad forwards eagerly instead of replaying them from a HIP graph")
+    p.add_argument("--no_graph_student", dest="graph_student", action="store_false",
+                   help="issue the student forward / backward (and the teacher side, K1, K4) launch by launch instead of replaying "
+                        "the step from HIP graphs (helper/step_graph.py)")
     p.add_argument("--miopen_find", default="on", choices=["on", "off"],
                    help="on = cudnn.benchmark as in the reference (MIOpen find mode: minutes at the first step of a new "
                         "shape); off = immediate mode with the shipped find-db")
