@@ -744,6 +744,347 @@ __global__ __launch_bounds__(256, 1) void infonce_flash_kernel(const uint4* __re
                                    l_part, x_part);
 }
 
+// ---- small batches (B <= 64: the reference's default --batch_size, BASELINE configs[4] per rank) ------------------------------
+// At B <= 64 the problem is HBM-bound (4B/2 = 128 flop per queue byte against a ridge of ~312) and the B = 256 decomposition leaves
+// two of a workgroup's four waves on pad rows while the other two run the full 2 x 1024 MFMA cycles per 32-key tile.  Here the four
+// waves of a workgroup are 2 row blocks x 2 KEY HALVES of every tile: wave (rb, kh) takes keys 16 kh .. 16 kh + 15 of each 32-key
+// tile for the query rows 32 rb .. 32 rb + 31 -- half the matrix work, half the LDS reads and half the softmax per wave and tile,
+// with the same tile ring, the same LDS image and the same DMA as the one-pass kernel (all four waves still fetch the whole
+// tile together).  No exchange between the halves: each wave runs its own online softmax over its keys and leaves its own
+// partial (m, l, max, O) as "virtual chunk" 2 * chunk + kh; the combine kernel merges them like any other chunks.
+//   scores : X[key, q] by v_mfma_f32_16x16x32_bf16 (A = 16 keys x 32 k by ds_read_b128, B = Q: two MFMAs per k-step for the 32
+//            query rows).  Lane l of the results holds A-rows 4 (l>>4) + r of column l & 15; ONE v_permlane16_swap per register
+//            pair (X0[r], X1[r]) leaves lane L with query row L & 31 and A-rows 8 (L>>5) + 0..3 (X0) / + 4..7 (X1).  The A-rows are
+//            fed from the tile's key rows in the order rho = {0-3, 8-11, 4-7, 12-15}, so that lane (q, h) ends up with keys
+//            {4h .. 4h+3} and {8 + 4h .. 8 + 4h + 3} of the wave's half -- exactly the k order key(0,h,j) = 8 (j>>2) + 4h + (j&3)
+//            in which the one-pass kernel's transposed reads deliver the B operand of
+//   P.K    : O[q, :] += P[q, 16 keys] . K_half  -- ONE v_mfma_f32_32x32x16_bf16 per 32-column tile (the 16 keys are its k).
+// Q comes from the same packed image (infonce_qpack_kernel / K1's proj epilogue), gathered per lane in the 16x16x32 B layout.
+template <int D>
+__global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __restrict__ qpack, const bf16_raw* __restrict__ queue,
+                                                               int B, int K, int tiles_per_chunk, int Bpad,
+                                                               uint4* __restrict__ o_part, float* __restrict__ m_part,
+                                                               float* __restrict__ l_part, float* __restrict__ x_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = D / 16;        // k-steps of the packed Q image
+    constexpr int KS2 = D / 32;       // k-steps of the 16x16x32 score product
+    constexpr int NCT = D / 32;       // 32-column tiles of O
+    constexpr int TILE_BYTES = KT * D * 2;
+    constexpr int PPW = D / 64;       // DMA pieces per wave and tile
+    static_assert(3 * PPW + 2 * KS2 <= 63, "vmcnt is a 6-bit counter");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = wave & 1, kh = wave >> 1;
+    const int n = lane & 31, h = lane >> 5, i16 = lane & 15, g = lane >> 4;
+    const int chunk = blockIdx.x;
+    const int ntiles = (K + KT - 1) / KT;
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(t0 + tiles_per_chunk, ntiles);
+    const DmaLane dl = dma_lane_terms<D>(lane, wave, (unsigned)(D * 2));
+    const long prow = (long)chunk * Bpad + rb * 32;
+    const bool live = rb * 32 < B;
+
+    // ---- Q fragments (B operand of the 16x16x32 product): lane l holds Q[32 rb + 16 m + (l&15)][32 s + 8 (l>>4) + j]
+    //      = element (k-step 2s + (g>>1), lane 16m + (l&15) + 32 (g&1)) of the packed image; inline asm, counted by hand
+    bf16x8 qf[2][KS2];
+    {
+        const char* qb = reinterpret_cast<const char*>(qpack + (long)rb * KS * 64) + (g >> 1) * 1024 + (g & 1) * 512 + i16 * 16;
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qf[m][s]) : "v"(qb + (s >> 1) * 4096), "n"((s & 1) * 2048 + m * 256) : "memory");
+        }
+    }
+    auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((unsigned)(t - t0) & (NBUF - 1)) * TILE_BYTES; };
+    const int npro = min(t1 - t0, NBUF - 1);                  // tiles requested up front: t0 .. t0+2 (t0+3 follows in tile t0's shadow)
+    auto issue_ring = [&]() __attribute__((always_inline)) {
+        int tb = t0;
+        asm volatile("" : "+s"(tb));
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j)
+            if (j < npro) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+    };
+    issue_ring();
+
+    f32x16 O[NCT];
+    float l_run = 0.f, mx = NEG_BIG, m_ref = NEG_BIG;
+    int ovf = 0;
+
+    // per-lane LDS offsets.  Row read (A operand, 16x16x32): key row rho(l & 15) + 16 kh, 16-B chunk 4 s + g of the row:
+    //   chunk ((s&3) << 2 | g) ^ swz(row) = lane part ^ ((s&3) << 6 in bytes); segment s >> 2 as the immediate.
+    const int arow = ((i16 & 3) | ((i16 & 4) << 1) | ((i16 & 8) >> 1)) + 16 * kh;          // rho: A-rows 0-3, 4-7, 8-11, 12-15 <- keys 0-3, 8-11, 4-7, 12-15
+    const int a_off = arow * 256 + (((swz(arow) & 12) | ((swz(arow) & 3) ^ g)) << 4);
+    // transposed read (B operand of P.K), as in the one-pass kernel; k-step 0 of the tile's half: + 16 kh rows
+    int b_off;
+    {
+        const int q4 = i16 >> 2, p = i16 & 3, g2 = (lane >> 4) & 1;
+        const int e = (2 * g2 + (p >> 1)) ^ h;
+        b_off = (4 * h + q4) * 256 + 8 * (p & 1) + (((q4 << 2) | e) << 4) + kh * 4096;
+    }
+    // exchange words of the two key halves of a row block (behind the ring and its 4 overflow words): row maxima
+    const unsigned xch_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(smem + NBUF * TILE_BYTES + 16);
+    const unsigned xch_mine = xch_base + ((rb * 2 + kh) * 32 + n) * 4, xch_other = xch_base + ((rb * 2 + (kh ^ 1)) * 32 + n) * 4;
+    constexpr int RD = 4;                                                                 // row reads in flight (k-steps)
+    constexpr int PF = 2;                                                                 // column tiles of transposed reads in flight
+    f32x4 kf[RD];
+    unsigned aa[4];
+    auto rd = [&](int s) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[s % RD]) : "v"(aa[s & 3]), "i"((s >> 2) * 8192) : "memory");
+    };
+    s16x4 kb[PF + 1][2];
+    unsigned ba[4][2];
+    auto issue_tr = [&](int c) __attribute__((always_inline)) {
+        s16x4* k2 = kb[c % (PF + 1)];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k2[0]) : "v"(ba[c & 3][0]), "i"((c >> 2) * 8192) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k2[1]) : "v"(ba[c & 3][1]), "i"((c >> 2) * 8192 + 2048) : "memory");
+    };
+    auto wait_lgkm = [&](int c) __attribute__((always_inline)) {
+        switch (c) {
+            case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        }
+    };
+    auto wait_tiles_in_flight = [&](int j) __attribute__((always_inline)) {
+        if (j >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+    // One pass over the chunk; `repass`: the references are the true row maxima of the first pass (cannot overflow).
+    auto run_pass = [&](auto repass_tag) __attribute__((always_inline)) {
+        constexpr bool repass = decltype(repass_tag)::value;
+        if constexpr (repass) issue_ring();
+        {
+            bf16x8 zq = bf16x8{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            asm volatile("" : "+v"(zq));
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                asm volatile("" : "+v"(zq));
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zq, zq, z, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l_run = 0.f;
+        mx = NEG_BIG;
+        ovf = 0;
+        wait_tiles_in_flight(npro - 1);                       // Q and tile t0 have landed
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) { asm volatile("" : "+v"(qf[0][s])); asm volatile("" : "+v"(qf[1][s])); }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = t0; t < t1; ++t) {
+            const char* buf = slot(t);
+            const bool refill = t + NBUF - 1 < t1;            // tile t+3 into the slot of tile t-1 (free since the last barrier)
+            const long rkey0 = (long)(t + NBUF - 1) * KT;
+            char* rbuf = slot(t + NBUF - 1);
+            // ---- scores of this wave's 16 keys x 32 query rows.  refill_tag: 0 = no refill, 1 = a full tile, 2 = the queue's last
+            //      (partial) tile -- chosen once per tile, not per DMA piece
+            f32x4 x0, x1;
+            auto score = [&](auto refill_tag) __attribute__((always_inline)) {
+                constexpr int REFILL = decltype(refill_tag)::value;
+                {
+                    const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) aa[c] = a0 ^ (c << 6);
+#pragma unroll
+                    for (int s = 0; s < RD; ++s) rd(s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int s = 0; s < KS2; ++s) {
+                    const int ahead = (KS2 - 1 - s) < (RD - 1) ? (KS2 - 1 - s) : (RD - 1);
+                    wait_lgkm(ahead);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // inline asm (the fragments are asm-loaded registers: nothing may copy them before the wait above); the two
+                    // accumulate chains alternate; the last MFMA carries the wait states in front of the VALU readers (8-pass: 12)
+                    if (s == 0) {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                    } else if (s == KS2 - 1) {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 11" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                    } else {
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + RD < KS2) rd(s + RD);
+                    if constexpr (REFILL != 0) {
+                        if ((s & 1) == 1) dma_piece<D, REFILL == 2>(s >> 1, dl, queue, rkey0, K, rbuf, wave, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (!refill) score(std::integral_constant<int, 0>{});
+            else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{});
+            else score(std::integral_constant<int, 1>{});
+            // first transposed reads of P.K while the softmax runs
+            {
+                const unsigned b0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + b_off;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    ba[c4][0] = b0 ^ (c4 << 6);
+                    ba[c4][1] = b0 ^ ((c4 << 6) | 32);
+                }
+#pragma unroll
+                for (int c = 0; c < PF; ++c) issue_tr(c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- lane (q = L & 31, h): keys 4h + r (xa) and 8 + 4h + r (xb) of the wave's half
+            float xa[4], xb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0[r]), __float_as_uint(x1[r]), false, false);
+                xa[r] = __uint_as_float(sw[0]);
+                xb[r] = __uint_as_float(sw[1]);
+            }
+            if ((t + 1) * KT > K) {                           // keys past K (the queue's last tile)
+                const int kbase = t * KT + 16 * kh + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kbase + r >= K) xa[r] = NEG_BIG;
+                    if (kbase + 8 + r >= K) xb[r] = NEG_BIG;
+                }
+            }
+            float tmax = fmaxf(fmaxf(fmaxf(xa[0], xa[1]), fmaxf(xa[2], xa[3])), fmaxf(fmaxf(xb[0], xb[1]), fmaxf(xb[2], xb[3])));
+            tmax = fmaxf(tmax, other_half(tmax));
+            mx = fmaxf(mx, tmax);
+            if (!repass && t == t0) {
+                // the two key halves of a row block share ONE fixed reference (the 32-key tile's row maximum + the margin, as the
+                // one-pass kernel): their O partials then add up without rescaling when the halves are merged behind the loop
+                // (inline asm + raw barrier: __syncthreads() would drain vmcnt, i.e. wait for the whole tile ring)
+                float other;
+                asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "v"(xch_mine), "v"(tmax) : "memory");
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(other) : "v"(xch_other) : "memory");
+                const float both = fmaxf(tmax, other);
+                m_ref = both > 0.5f * NEG_BIG ? both + REF_MARGIN : 0.f;
+            }
+            ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xa[r] = __builtin_amdgcn_exp2f(xa[r] - m_ref);
+                xb[r] = __builtin_amdgcn_exp2f(xb[r] - m_ref);
+                psum += xa[r] + xb[r];
+            }
+            l_run += psum;
+            const bf16x8 pa = bf16x8{(__bf16)xa[0], (__bf16)xa[1], (__bf16)xa[2], (__bf16)xa[3],
+                                     (__bf16)xb[0], (__bf16)xb[1], (__bf16)xb[2], (__bf16)xb[3]};
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- O[q, cols] += P[q, 16 keys] . K_half[16 keys, cols]
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
+                wait_lgkm(2 * ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                s16x4* k2 = kb[c % (PF + 1)];
+                const s16x8 kk = __builtin_shufflevector(k2[0], k2[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, kk), O[c], 0, 0, 0);
+                if (c + PF < NCT) issue_tr(c + PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // tile t+1 must have landed (t+2, t+3 may stay in flight); every wave is done with this slot
+            wait_tiles_in_flight(max(min(t + NBUF - 1, t1 - 1) - (t + 1), 0));
+            __builtin_amdgcn_s_barrier();
+            }
+    };
+    run_pass(std::false_type{});
+    {
+        int* wflag = reinterpret_cast<int*>(smem + NBUF * TILE_BYTES);         // 4 words behind the ring
+        const int any = __any(ovf) ? 1 : 0;
+        if (lane == 0) wflag[wave] = any;
+        __syncthreads();
+        if ((wflag[0] | wflag[1] | wflag[2] | wflag[3]) != 0) {
+            float* xch = reinterpret_cast<float*>(smem + NBUF * TILE_BYTES + 16);
+            if (h == 0) xch[(rb * 2 + kh) * 32 + n] = mx;                        // (mx: already merged over the lane halves per tile)
+            __syncthreads();                                                     // flags read, maxima written, ring idle
+            m_ref = fmaxf(mx, xch[(rb * 2 + (kh ^ 1)) * 32 + n]);               // true row maxima over BOTH key halves
+            if (m_ref < 0.5f * NEG_BIG) m_ref = 0.f;
+            __syncthreads();
+            run_pass(std::true_type{});
+        }
+    }
+    // ---- merge the key halves (same reference: plain sums) through the idle ring: each wave of a pair gives the other one half
+    //      of its column tiles -- rounded to bf16, the storage format of the partials, in store order -- and sums / stores the half
+    //      it keeps, so both waves share the tail (one wave merging and storing everything was 1.5 us slower)
+    float l_tot = l_run + other_half(l_run);
+    constexpr int HCT = NCT / 2;
+    static_assert(NCT % 2 == 0, "column tiles split evenly over the two key halves");
+    uint4* xo_mine = reinterpret_cast<uint4*>(smem) + (rb * 2 + kh) * (HCT * 2 * 64);         // 16 KiB per wave at D = 512
+    const uint4* xo_other = reinterpret_cast<const uint4*>(smem) + (rb * 2 + (kh ^ 1)) * (HCT * 2 * 64);
+    float* xs = reinterpret_cast<float*>(smem + 4 * HCT * 2 * 64 * 16) + rb * 64;             // l [32], max [32] of kh = 1
+    auto packed = [&](int c, int g2) __attribute__((always_inline)) -> uint4 {
+        uint4 v;
+        v.x = (unsigned)f32_to_bf16(O[c][8 * g2 + 0]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 1]) << 16);
+        v.y = (unsigned)f32_to_bf16(O[c][8 * g2 + 2]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 3]) << 16);
+        v.z = (unsigned)f32_to_bf16(O[c][8 * g2 + 4]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 5]) << 16);
+        v.w = (unsigned)f32_to_bf16(O[c][8 * g2 + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 7]) << 16);
+        return v;
+    };
+    auto add_packed = [&](int c, int g2, const uint4& v) __attribute__((always_inline)) {
+        O[c][8 * g2 + 0] += __uint_as_float(v.x << 16); O[c][8 * g2 + 1] += __uint_as_float(v.x & 0xffff0000u);
+        O[c][8 * g2 + 2] += __uint_as_float(v.y << 16); O[c][8 * g2 + 3] += __uint_as_float(v.y & 0xffff0000u);
+        O[c][8 * g2 + 4] += __uint_as_float(v.z << 16); O[c][8 * g2 + 5] += __uint_as_float(v.z & 0xffff0000u);
+        O[c][8 * g2 + 6] += __uint_as_float(v.w << 16); O[c][8 * g2 + 7] += __uint_as_float(v.w & 0xffff0000u);
+    };
+    uint4* dst = o_part + ((long)chunk * (Bpad / 32) + rb) * (long)(NCT * 2 * 64) + lane;
+    // keep_tag: the half of the column tiles this wave keeps (0: tiles 0 .. HCT-1, 1: HCT .. NCT-1) -- compile-time register indices
+    auto give = [&](auto keep_tag) __attribute__((always_inline)) {
+        constexpr int G0 = decltype(keep_tag)::value ? 0 : HCT;
+#pragma unroll
+        for (int cc = 0; cc < HCT; ++cc) {
+            xo_mine[(cc * 2 + 0) * 64 + lane] = packed(G0 + cc, 0);
+            xo_mine[(cc * 2 + 1) * 64 + lane] = packed(G0 + cc, 1);
+            __builtin_amdgcn_sched_barrier(0);       // (tile by tile: left alone hipcc reads all 256 accumulators out first and spills)
+        }
+    };
+    auto take = [&](auto keep_tag) __attribute__((always_inline)) {
+        constexpr int K0 = decltype(keep_tag)::value ? HCT : 0;
+#pragma unroll
+        for (int c2 = 0; c2 < HCT; c2 += 2) {                                          // four requests, then their sums and stores
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xo_other[(c2 * 2 + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                add_packed(K0 + c2 + (u >> 1), u & 1, v[u]);
+                dst[((K0 + c2 + (u >> 1)) * 2 + (u & 1)) * 64] = packed(K0 + c2 + (u >> 1), u & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    __syncthreads();                                                                   // every wave is done with the ring
+    if (live) {
+        if (kh == 0) give(std::false_type{});
+        else give(std::true_type{});
+    }
+    if (kh == 1 && h == 0) { xs[n] = l_tot; xs[32 + n] = mx; }
+    __syncthreads();
+    if (kh == 0) {
+        l_tot += xs[n];
+        mx = fmaxf(mx, xs[32 + n]);
+        if (h == 0) {
+            m_part[prow + n] = m_ref;
+            l_part[prow + n] = l_tot;
+            x_part[prow + n] = mx;
+        }
+    }
+    if (live) {
+        if (kh == 0) take(std::false_type{});
+        else take(std::true_type{});
+    }
+}
+
 // ---- wide queues (d > 512): slab passes ------------------------------------------------------------------------
 template <int D, int MODE>
 __global__ __launch_bounds__(256, 1) void infonce_slab_kernel(const uint4* __restrict__ qpack, const bf16_raw* __restrict__ queue,
@@ -1358,6 +1699,7 @@ __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __
 // Scalars: 32 threads per row.  dq: the 256 threads are 8 chunk-groups x 32 columns, one 16-B load (8 rows of a column) per
 // thread and chunk; the chunk-groups are summed through LDS in a fixed order (bitwise reproducible).
 constexpr int COMBINE_MAX_CHUNKS = 1024;
+constexpr int SMALL_B_MAX = 64;      // batches up to this take infonce_small_kernel (with dq)
 __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q, const float* __restrict__ k,
                                                      int B, int D, float inv_T, int nchunk, int Bpad,
                                                      const uint4* __restrict__ o_part,
@@ -1401,7 +1743,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
         // The statistics are three dependent sweeps (positive logit; maxima; weights and sum): with up to 128 chunks every
         // partial a lane needs is requested up front, next to the q / k rows, so the block pays ONE global round trip, not three
         // (the kernel is latency-bound: 6.5 us of its 13.9 were this prologue).
-        constexpr int MC = 4;
+        constexpr int MC = 8;                      // (256 chunks -- the small-batch plan -- still take the one-round-trip path)
         const bool small = nchunk <= 32 * MC;
         float mv[MC], xv[MC], lv[MC];
 #pragma unroll
@@ -1677,12 +2019,13 @@ namespace {
 // dynamic-LDS opt-in of every instantiation, once per process (hipFuncSetAttribute is not a stream operation)
 std::once_flag g_lds_attr_once;
 void set_lds_attrs() {
-    const int mx = NBUF * KT * 512 * 2 + 16;
+    const int mx = NBUF * KT * 512 * 2 + 16 + 512;
 #define MOMA_SET_LDS(DD)                                                                                                        \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);     \
     (void)hipFuncSetAttribute((const void*)infonce_flash_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);    \
     (void)hipFuncSetAttribute((const void*)infonce_flash_multi_kernel<DD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);   \
     (void)hipFuncSetAttribute((const void*)infonce_flash_multi_kernel<DD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);  \
+    (void)hipFuncSetAttribute((const void*)infonce_small_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);           \
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);         \
     (void)hipFuncSetAttribute((const void*)infonce_slab_kernel<DD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx)
     MOMA_SET_LDS(512); MOMA_SET_LDS(384); MOMA_SET_LDS(256); MOMA_SET_LDS(128);
@@ -1707,6 +2050,39 @@ size_t infonce_qpack_bytes(int B, int d) {
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed, hipEvent_t ev_call_end) {
+    if (B <= SMALL_B_MAX && dq != nullptr && one_pass_dim(d)) {
+        // ---- small batches: key-half split (infonce_small_kernel), two virtual chunks per workgroup, 64 padded rows
+        const int ntiles = (K + KT - 1) / KT;
+        const int tpc = (ntiles + 255) / 256;                              // ~1 workgroup per CU
+        const int nwg = (ntiles + tpc - 1) / tpc;
+        const int Bp = 64;
+        const size_t rows = (size_t)nwg * Bp;                              // (half of plan(B, K).nchunk * 128: the workspace formula holds)
+        float* m_part = (float*)ws;
+        float* l_part = m_part + rows;
+        float* x_part = l_part + rows;
+        uint4* o_part = (uint4*)(((uintptr_t)(x_part + 2 * rows) + 255) & ~(uintptr_t)255);
+        uint4* qpack = (uint4*)(((uintptr_t)((char*)o_part + rows * d * 2) + 255) & ~(uintptr_t)255);
+        std::call_once(g_lds_attr_once, set_lds_attrs);
+        const float scale_log2 = inv_T * 1.4426950408889634f;
+        const bf16_raw* qu = (const bf16_raw*)queue;
+        const size_t lds = (size_t)NBUF * KT * d * 2 + 16 + 512;          // ring, overflow words, exchange words of the key halves
+        if (q_packed != nullptr) qpack = (uint4*)q_packed;
+#define MOMA_SMALL_LAUNCH(DD)                                                                                                  \
+        do {                                                                                                                   \
+            if (q_packed == nullptr) hipLaunchKernelGGL((infonce_qpack_kernel<DD>), dim3(((Bp / 32) * (DD / 16) + 3) / 4), dim3(256), 0, st, q, B, d, 0, scale_log2, qpack, Bp / 32); \
+            hipExtLaunchKernelGGL((infonce_small_kernel<DD>), dim3(nwg), dim3(256), lds, st, ev_begin, ev_end, 0, qpack, qu, B, K, tpc, Bp, o_part, m_part, l_part, x_part); \
+        } while (0)
+        if (d == 512) MOMA_SMALL_LAUNCH(512);
+        else if (d == 384) MOMA_SMALL_LAUNCH(384);
+        else if (d == 256) MOMA_SMALL_LAUNCH(256);
+        else MOMA_SMALL_LAUNCH(128);
+#undef MOMA_SMALL_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(Bp / 8, d / 32), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+                              d, inv_T, nwg, Bp, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
+        return hipGetLastError();
+    }
     const FlashPlan p = plan(B, K);
     if (p.nchunk > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;
     const size_t rows = (size_t)p.nchunk * p.Bpad;

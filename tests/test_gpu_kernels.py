@@ -270,6 +270,78 @@ def test_infonce_flash_overflow_repass(ops, scale, d, grad):
         np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
 
 
+@pytest.mark.parametrize("B,d,K", [(64, 512, 65536), (64, 512, 4100), (33, 256, 1000), (8, 128, 40), (1, 384, 9000), (40, 512, 20000),
+                                   (64, 384, 65536), (17, 512, 8200), (64, 128, 33), (97, 512, 4100), (130, 512, 9000)])
+def test_infonce_small_batch_and_ragged_rows_on_poisoned_workspace(ops, B, d, K):
+    """B <= 64 (the reference's default --batch_size, train_student_moma.py:51; BASELINE configs[4] per rank) runs the key-half-split
+    instantiation of the one-pass kernel (infonce_small_kernel: 16x16x32 score MFMAs, each wave of a workgroup on 16 of a tile's 32
+    keys, two virtual chunks per workgroup); B = 97 / 130 are ragged row blocks of the B = 256 schedule, whose pad-row waves store
+    nothing (the combine must never read what was not written).  Through caller-owned buffers (ops.K2Buffers) whose
+    workspace is poisoned with NaN before the call: loss / lse / top-1 / dq against the fp64 oracle; K not a multiple of the tile
+    (a key half that lies past K entirely), K smaller than one tile, one row."""
+    rng = np.random.default_rng(B * 3 + d + K)
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    # a few rows aligned with queue rows (peaked softmax: the sum_j p_bj queue_j part of dq is O(1)), one of them in the LAST tile
+    hot = rng.integers(0, K, size=min(B, 6))
+    hot[0] = K - 1
+    for b, j in enumerate(hot):
+        q[b] = (1.5 * queue[j] + 0.1 * q[b]).astype(np.float32)
+    T = 0.15
+    tq, tk, tqueue = _t(q), _t(k), _t(queue, torch.bfloat16)
+    qe = tqueue.float().cpu().numpy()
+    ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, qe, T) * B
+    out = ops.K2Buffers(B, d, K, torch.bfloat16, "bf16", tq.device)
+    for rep in range(2):                                                    # (twice: the second call meets the first one's leftovers)
+        out.ws.view(torch.int16).fill_(0x7FC0 if rep == 0 else -1)          # bf16 / fp32 NaN patterns everywhere
+        out.dq.fill_(float("nan")); out.loss_rows.fill_(float("nan")); out.lse.fill_(float("nan")); out.top1.fill_(-7)
+        ops.infonce_fused_into(tq, tk, tqueue, T, "bf16", None, out)
+        torch.cuda.synchronize()
+        lse, loss_rows, dq = out.lse.cpu().numpy(), out.loss_rows.cpu().numpy(), out.dq.cpu().numpy()
+        assert np.all(np.isfinite(lse)) and np.all(np.isfinite(dq)) and np.all(np.isfinite(loss_rows))
+        np.testing.assert_allclose(lse, ref["lse"], rtol=1e-3, atol=5e-3)
+        assert abs(loss_rows.mean() - ref["loss"]) < 1e-3 * max(1.0, abs(ref["loss"]))
+        np.testing.assert_allclose(dq, ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
+        t1 = out.top1.cpu().numpy()
+        assert set(np.unique(t1)) <= {0, 1}
+        sure = np.abs(np.sort(O.compute_logit(q, k, qe, T, dtype=np.float64), axis=1)[:, -1] - O.compute_logit(q, k, qe, T, dtype=np.float64)[:, 0]) > 0.5
+        assert np.array_equal(t1[sure].astype(bool), ref["top1"][sure])     # (rows whose positive logit is not within bf16 noise of the max)
+    # the autograd entry gives the same numbers (it allocates its own buffers)
+    tq2 = _t(q).requires_grad_(True)
+    lr2, lse2, _ = ops.infonce_fused(tq2, tk, tqueue, T, "bf16")
+    lr2.sum().backward()
+    assert torch.equal(lse2, out.lse) and torch.equal(tq2.grad, out.dq)
+
+
+@pytest.mark.parametrize("d", [128, 512])
+@pytest.mark.parametrize("scale", [30.0, 10.0])
+def test_infonce_small_batch_overflow_repass(ops, scale, d):
+    """The rare branch of the small-batch kernel (guide rule 26): chunks of 3 tiles (K = 20000), a key in the LAST tile of its chunk
+    -- one in the first key half of its tile, one in the second -- beats the fixed reference of its wave (first tile's max + 32) by
+    ~290 log2 units (scale 30: the workgroup repeats its chunk with the true row maxima) or ~96 (scale 10: one pass carries it)."""
+    rng = np.random.default_rng(11)
+    B, K, T = 40, 20000, 0.15
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
+    # workgroup w covers tiles 3w .. 3w+2 = keys 96 w .. 96 w + 95: key 96*20 + 64 + 5 (third tile, first half), 96*101 + 64 + 27 (second half)
+    queue[96 * 20 + 69] = scale * q[5] / np.linalg.norm(q[5])
+    queue[96 * 101 + 91] = (scale - 5.0) * q[37] / np.linalg.norm(q[37])
+    tq = _t(q).requires_grad_(True)
+    tqueue = _t(queue, torch.bfloat16)
+    qe = tqueue.float().cpu().numpy()
+    ref = O.infonce_loss(O.compute_logit(q, k, qe, T, dtype=np.float64))
+    ref_dq = O.infonce_grad(q, k, qe, T) * B
+    loss_rows, lse, top1 = ops.infonce_fused(tq, _t(k), tqueue, T, "bf16")
+    np.testing.assert_allclose(lse.cpu().numpy(), ref["lse"], rtol=1e-2, atol=2e-2)
+    assert np.all(np.isfinite(lse.cpu().numpy()))
+    assert abs(loss_rows.mean().item() - ref["loss"]) < 1e-2 * abs(ref["loss"])
+    loss_rows.sum().backward()
+    np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
+
+
 @pytest.mark.parametrize("B,d,K", [(256, 512, 65536), (100, 256, 5000), (33, 128, 777), (8, 512, 40), (1, 128, 100), (64, 512, 4097)])
 def test_infonce_f32_policy_is_one_pass(ops, B, d, K):
     """The reference's OWN arithmetic (fp32; MoMA/mem_moco.py:29-49,77-100 + CrossEntropy) as one pass over the fp32 queue on the
