@@ -517,7 +517,8 @@ def main():
                                              "call (3 launches each; atts_k + atts_queue run as ONE group of 3 launches on the side stream); "
                                              "in-kernel matrix-pipe shares are in pmc.k1_*"}
         roof["other"] = other
-        kname = ("infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)" if d <= 512 else
+        kname = (("infonce_small_kernel (K2 one pass over the queue, key-half split for B <= 64; moma_infonce_fused)" if a.batch_size <= 64 else
+                  "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)") if d <= 512 else
                  "infonce_wide_scores_kernel + infonce_wide_pv2_kernel (K2 over a wide queue, d > 512: the two passes over the queue; "
                  "like the one-pass line the Q pre-pack in front and the combine behind are in whole_call_ms only)")
         roof.update({"kernel": kname,

@@ -49,20 +49,32 @@ F32Plan f32_plan(int B, int K) {
     return p;
 }
 
-// CT = column tiles (of 32) per wave: d = 128 CT.  LDS: per wave two tile buffers of 32 keys x 128 CT bytes | X exchange 16 KiB | flag
-template <int CT> constexpr int f32_lds_bytes() { return 4 * 2 * 32 * 128 * CT + 16384 + 16; }
+// CT = column tiles (of 32) per wave: d = 128 CT.  The wave's slab of a key tile goes through LDS in NSEG = CT / SC SEGMENTS of SC
+// column tiles (SC in {1, 2, 4}: power-of-two row pitch for the xor-stepped addresses): d = 128 / 256 / 512 are one segment
+// (SC = CT), wider rows -- the reference CLI's default --head None: 384, 768, 1280, also 1024 -- stream 3 / 3 / 5 / 2
+// segments per tile through the same two buffers per wave.  The scores need every segment before the softmax and P.K needs them
+// again after it, so per tile the wave's DMA stream is S_0 .. S_{n-1}, P_{n-2} .. P_0 (P_{n-1} finds its segment still in place):
+// 2n - 1 segment fetches, the repeats from L2; the kernel is bound by the f32 matrix rate, 2.3x above its HBM side, so the extra
+// L2 -> LDS traffic is affordable where a materialised [B,K+1] logits matrix is not.
+// LDS: per wave two segment buffers of 32 keys x 128 SC bytes | X exchange 16 KiB | flag
+template <int SC> constexpr int f32_lds_bytes() { return 4 * 2 * 32 * 128 * SC + 16384 + 16; }
 
-template <int CT, bool WITH_DQ>
+template <int CT, int SC, bool WITH_DQ>
 __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __restrict__ q, const float* __restrict__ queue, int B,
                                                                 int K, float scale_log2, int nrb, int nchunk, int tiles_per_chunk,
                                                                 int Bpad, float* __restrict__ o_part, float* __restrict__ m_part,
                                                                 float* __restrict__ l_part, float* __restrict__ x_part) {
+    static_assert(CT % SC == 0 && (SC == 1 || SC == 2 || SC == 4), "segments of 1 / 2 / 4 column tiles");
+    constexpr int NSEG = CT / SC;                 // segments of the wave's slab
     constexpr int SLAB = 32 * CT;                 // columns per wave
-    constexpr int PITCH = SLAB * 4;               // bytes per key row of a wave's tile image
+    constexpr int SEGC = 32 * SC;                 // columns per segment
+    constexpr int PITCH = SEGC * 4;               // bytes per key row of a segment image
     constexpr int NCH = PITCH / 16;               // 16-B chunks per row: 8 / 16 / 32
-    constexpr int G = SLAB / 8;                   // groups of 8 columns = 4 MFMAs each
-    constexpr int NDMA = 32 * PITCH / 1024;       // LDS-DMA instructions per tile and wave
+    constexpr int G = SEGC / 8;                   // groups of 8 columns per segment = 4 MFMAs each
+    constexpr int GT = SLAB / 8;                  // ... per slab
+    constexpr int NDMA = 32 * PITCH / 1024;       // LDS-DMA instructions per segment and wave
     constexpr int D = 4 * SLAB;
+    constexpr int JOBS = WITH_DQ ? 2 * NSEG - 1 : NSEG;      // segment fetches per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,20 +100,20 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
     const int slab0 = wave * SLAB;
 
     // resident Q slab: lane (q = n, h) holds Q[q][slab0 + 8 g + 4 h + m], pre-scaled by log2(e) / T
-    float qr[G][4];
+    float qr[GT][4];
     {
         const int row = rb * 32 + n;
         const float sc = row < B ? scale_log2 : 0.f;          // rows past B: zero queries (unconditional loads from a clamped row)
         const float* qp = q + (long)min(row, B - 1) * D + slab0 + 4 * h;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < GT; ++g) {
             const float4 v = *reinterpret_cast<const float4*>(qp + 8 * g);
             qr[g][0] = v.x * sc; qr[g][1] = v.y * sc; qr[g][2] = v.z * sc; qr[g][3] = v.w * sc;
         }
     }
     // LDS-DMA of this wave's slab of tile t: piece p covers image bytes [1024 p, 1024 p + 1024); lane L -> row, chunk position;
     // position cp of a row holds the row's chunk cp ^ (row & (NCH - 1) & 15)   (bank spread for the ds_read_b128 row reads)
-    auto dma_tile = [&](int t, int b) {
+    auto dma_seg = [&](int t, int seg, int b) __attribute__((always_inline)) {
         char* dst = bufs + b * (32 * PITCH);
 #pragma unroll
         for (int p = 0; p < NDMA; ++p) {
@@ -109,8 +121,20 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
             const int row = o / PITCH, cp = (o % PITCH) >> 4;
             const int ch = cp ^ (row & (NCH - 1) & 15);
             const long key = min((long)t * KT + row, (long)K - 1);            // keys past K: clamped, masked below
-            const char* src = reinterpret_cast<const char*>(queue + key * D + slab0) + ch * 16;
+            const char* src = reinterpret_cast<const char*>(queue + key * D + slab0 + seg * SEGC) + ch * 16;
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+    // The wave's DMA stream: job j of tile t (j = 0 .. JOBS-1) fetches segment seg_of(j) into buffer (tile index * JOBS + j) & 1;
+    // `advance` issues the job AFTER (t, j) -- possibly the next tile's first -- and waits until job (t, j) itself has landed.
+    auto seg_of = [](int j) { return j < NSEG ? j : 2 * NSEG - 2 - j; };
+    auto advance = [&](int t, int j) __attribute__((always_inline)) {
+        const int jn = j + 1 < JOBS ? j + 1 : 0, tn = j + 1 < JOBS ? t : t + 1;
+        if (tn < t1) {
+            dma_seg(tn, seg_of(jn), (((tn - t0) * JOBS + jn) & 1));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
     // Lane terms of the two kinds of LDS reads, so that every read is ONE of a few base registers plus a compile-time constant
@@ -135,26 +159,22 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
         if (tid == 0) *flag = 0u;
-        dma_tile(t0, 0);
+        dma_seg(t0, 0, 0);
         for (int t = t0; t < t1; ++t) {
-            const int b = (t - t0) & 1;
-            // (measured and not taken: the next tile's 16 pieces issued one per group of four score MFMAs instead of here -- 389 vs
-            //  377 us with dq, 233 vs 210 forward-only; the pieces by inline asm with one base + one xor each instead of the
-            //  builtin's ~12 instructions -- 384 / 212 us, no change: the DMA issue is not what the tile waits for)
-            if (t + 1 < t1) {
-                dma_tile(t + 1, b ^ 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            const char* img = bufs + b * (32 * PITCH);
-            // ---- partial scores over the wave's slab
+            const int jb = (t - t0) * JOBS;                                   // (parity of) this tile's first DMA job
+            // ---- partial scores over the wave's slab, segment by segment
+            // (measured at one segment and not taken: the next tile's 16 pieces issued one per group of four score MFMAs instead of
+            //  up front -- 389 vs 377 us with dq, 233 vs 210 forward-only; the pieces by inline asm with one base + one xor each
+            //  instead of the builtin's ~12 instructions -- 384 / 212 us, no change: the DMA issue is not what the tile waits for)
             f32x16 x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = 0.f;
             // (the LDS reads of both products are inline asm with counted waits: left to hipcc every read is sunk to its MFMA and
             //  waited for with lgkmcnt(0) -- one exposed LDS round trip per MFMA pair, measured 496 us instead of the 219 us bound)
-            {
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                advance(t, sg);                                               // next fetch on its way, this segment landed
+                const char* img = bufs + ((jb + sg) & 1) * (32 * PITCH);
                 const unsigned ab = lds_addr(img) + a_base;
                 f32x4 kf[2];
                 asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(ab) : "memory");
@@ -168,10 +188,10 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const f32x4 f = kf[g & 1];
-                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0], qr[g][0], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1], qr[g][1], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[2], qr[g][2], x, 0, 0, 0);
-                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[3], qr[g][3], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0], qr[sg * G + g][0], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1], qr[sg * G + g][1], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[2], qr[sg * G + g][2], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(f[3], qr[sg * G + g][3], x, 0, 0, 0);
                 }
             }
             // ---- exchange: every wave sums the four partial tiles in the same order
@@ -214,40 +234,48 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
             ps += other_half(ps);
             l_run += ps;
             // ---- O_w += P . K_tile[:, slab]: A = p (lane (q, h), k-step s <-> register s: key (s&3) + 8 (s>>2) + 4 h),
-            //      B = K[key(s, h)][slab column 32 c + n] by ds_read_b32
+            //      B = K[key(s, h)][slab column 32 c + n] by ds_read_b32; segments in REVERSE order (the last score segment is
+            //      still in its buffer; the others are fetched again -- L2 hits)
             if constexpr (WITH_DQ) {
                 constexpr int HB = NCH > 8 ? 1 : 0;            // (with 8 chunks per row the swizzle has no bit 3)
-                unsigned pb[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pb[j] = lds_addr(img) + pv_base[j];
-                float kv[2][CT];
-                auto issue = [&](int s) __attribute__((always_inline)) {
+                for (int u = 0; u < NSEG; ++u) {
+                    const int sg = NSEG - 1 - u, j = NSEG - 1 + u;               // segment, and the DMA job that brought / brings it
+                    if (u > 0) advance(t, j);
+                    const char* img = bufs + ((jb + j) & 1) * (32 * PITCH);
+                    unsigned pb[4];
 #pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kv[s & 1][c]) : "v"(pb[s & 3]),
-                                     "n"(((s & 3) + 8 * (s >> 2)) * PITCH + 128 * (c ^ (((s >> 2) & 1) * HB))) : "memory");
-                };
-                auto wait_for = [&](int s, bool more) __attribute__((always_inline)) {
-                    // the CT reads of step s are complete once at most the CT younger ones (step s + 1) are outstanding
-                    if constexpr (CT == 4) {
-                        if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]), "+v"(kv[s & 1][2]), "+v"(kv[s & 1][3]) : : "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]), "+v"(kv[s & 1][2]), "+v"(kv[s & 1][3]) : : "memory");
-                    } else if constexpr (CT == 2) {
-                        if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]) : : "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]) : : "memory");
-                    } else {
-                        if (more) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kv[s & 1][0]) : : "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]) : : "memory");
+                    for (int jj = 0; jj < 4; ++jj) pb[jj] = lds_addr(img) + pv_base[jj];
+                    float kv[2][SC];
+                    auto issue = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int c = 0; c < SC; ++c)
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kv[s & 1][c]) : "v"(pb[s & 3]),
+                                         "n"(((s & 3) + 8 * (s >> 2)) * PITCH + 128 * (c ^ (((s >> 2) & 1) * HB))) : "memory");
+                    };
+                    auto wait_for = [&](int s, bool more) __attribute__((always_inline)) {
+                        // the SC reads of step s are complete once at most the SC younger ones (step s + 1) are outstanding
+                        if constexpr (SC == 4) {
+                            if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]), "+v"(kv[s & 1][2]), "+v"(kv[s & 1][3]) : : "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]), "+v"(kv[s & 1][2]), "+v"(kv[s & 1][3]) : : "memory");
+                        } else if constexpr (SC == 2) {
+                            if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]) : : "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]), "+v"(kv[s & 1][1]) : : "memory");
+                        } else {
+                            if (more) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kv[s & 1][0]) : : "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[s & 1][0]) : : "memory");
+                        }
+                    };
+                    issue(0);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {             // the B values of step s + 1 are requested ahead of step s's MFMAs
+                        if (s + 1 < 16) issue(s + 1);
+                        wait_for(s, s + 1 < 16);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int c = 0; c < SC; ++c)
+                            O[sg * SC + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], kv[s & 1][c], O[sg * SC + c], 0, 0, 0);
                     }
-                };
-                issue(0);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {                 // the B values of step s + 1 are requested ahead of step s's MFMAs
-                    if (s + 1 < 16) issue(s + 1);
-                    wait_for(s, s + 1 < 16);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], kv[s & 1][c], O[c], 0, 0, 0);
                 }
             }
             asm volatile("" ::: "memory");
@@ -335,16 +363,20 @@ __global__ __launch_bounds__(256) void infonce_f32_combine_kernel(const float* _
 
 std::once_flag g_f32_attr_once;
 void set_f32_attrs() {
-#define MOMA_F32_ATTR(CT)                                                                                                         \
-    (void)hipFuncSetAttribute((const void*)infonce_f32_flash_kernel<CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, f32_lds_bytes<CT>()); \
-    (void)hipFuncSetAttribute((const void*)infonce_f32_flash_kernel<CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, f32_lds_bytes<CT>())
-    MOMA_F32_ATTR(1); MOMA_F32_ATTR(2); MOMA_F32_ATTR(4);
+#define MOMA_F32_ATTR(CT, SC)                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)infonce_f32_flash_kernel<CT, SC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, f32_lds_bytes<SC>()); \
+    (void)hipFuncSetAttribute((const void*)infonce_f32_flash_kernel<CT, SC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, f32_lds_bytes<SC>())
+    MOMA_F32_ATTR(1, 1); MOMA_F32_ATTR(2, 2); MOMA_F32_ATTR(4, 4);
+    MOMA_F32_ATTR(3, 1); MOMA_F32_ATTR(6, 2); MOMA_F32_ATTR(8, 4); MOMA_F32_ATTR(10, 2);
 #undef MOMA_F32_ATTR
 }
 }  // namespace
 
+// widths of the one-pass fp32 kernel: (column tiles per wave, per segment) = (d / 128, SC)
+static bool f32_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024 || d == 1280; }      // (d = 1536: 12 column tiles per wave spill; d = 2048: Q + O alone are the register file)
+
 bool infonce_f32_flash_supported(int B, int d, int K, int qdtype, int prec) {
-    return prec == MOMA_PREC_F32 && qdtype == MOMA_DT_F32 && (d == 128 || d == 256 || d == 512) && B >= 1 && K >= 1 &&
+    return prec == MOMA_PREC_F32 && qdtype == MOMA_DT_F32 && f32_dim(d) && B >= 1 && K >= 1 &&
            f32_plan(B, K).nchunk <= 4096;
 }
 
@@ -367,16 +399,23 @@ hipError_t launch_infonce_f32_flash(const float* q, const float* k, const float*
     const float scale_log2 = inv_T * 1.4426950408889634f;
     const dim3 grid(p.nrb * p.nchunk), block(256);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
-#define MOMA_F32_LAUNCH(CT)                                                                                                       \
+#define MOMA_F32_LAUNCH(CT, SC)                                                                                                   \
     do {                                                                                                                          \
-        if (dq) hipLaunchKernelGGL((infonce_f32_flash_kernel<CT, true>), grid, block, f32_lds_bytes<CT>(), st, q, queue, B, K, scale_log2, \
+        if (dq) hipLaunchKernelGGL((infonce_f32_flash_kernel<CT, SC, true>), grid, block, f32_lds_bytes<SC>(), st, q, queue, B, K, scale_log2, \
                                    p.nrb, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part);                  \
-        else hipLaunchKernelGGL((infonce_f32_flash_kernel<CT, false>), grid, block, f32_lds_bytes<CT>(), st, q, queue, B, K, scale_log2, \
+        else hipLaunchKernelGGL((infonce_f32_flash_kernel<CT, SC, false>), grid, block, f32_lds_bytes<SC>(), st, q, queue, B, K, scale_log2, \
                                 p.nrb, p.nchunk, p.tiles_per_chunk, p.Bpad, o_part, m_part, l_part, x_part);                     \
     } while (0)
-    if (d == 512) MOMA_F32_LAUNCH(4);
-    else if (d == 256) MOMA_F32_LAUNCH(2);
-    else MOMA_F32_LAUNCH(1);
+    switch (d) {
+        case 128: MOMA_F32_LAUNCH(1, 1); break;
+        case 256: MOMA_F32_LAUNCH(2, 2); break;
+        case 384: MOMA_F32_LAUNCH(3, 1); break;
+        case 512: MOMA_F32_LAUNCH(4, 4); break;
+        case 768: MOMA_F32_LAUNCH(6, 2); break;
+        case 1024: MOMA_F32_LAUNCH(8, 4); break;
+        case 1280: MOMA_F32_LAUNCH(10, 2); break;
+        default: return hipErrorInvalidValue;
+    }
 #undef MOMA_F32_LAUNCH
     if (ev_end) (void)hipEventRecord(ev_end, st);
     hipError_t e = hipGetLastError();

@@ -1,9 +1,11 @@
-"""K2 under the exact-fp32 policy at the benchmark shape: one-pass kernel time (fp32 queue)."""
+"""K2 under the exact-fp32 policy: one-pass kernel time (fp32 queue).  usage: python scripts/bench_k2_f32.py [B] [d] [K]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from moma_amd import ops
-B, d, K = 256, 512, 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 torch.manual_seed(0)
 q = torch.nn.functional.normalize(torch.randn(B, d, device="cuda"))
 k = torch.nn.functional.normalize(q + 0.3 * torch.randn(B, d, device="cuda"))

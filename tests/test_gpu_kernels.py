@@ -342,11 +342,14 @@ def test_infonce_small_batch_overflow_repass(ops, scale, d):
     np.testing.assert_allclose(tq.grad.cpu().numpy(), ref_dq, rtol=0, atol=2e-2 * np.abs(ref_dq).max())
 
 
-@pytest.mark.parametrize("B,d,K", [(256, 512, 65536), (100, 256, 5000), (33, 128, 777), (8, 512, 40), (1, 128, 100), (64, 512, 4097)])
+@pytest.mark.parametrize("B,d,K", [(256, 512, 65536), (100, 256, 5000), (33, 128, 777), (8, 512, 40), (1, 128, 100), (64, 512, 4097),
+                                   (100, 384, 5000), (70, 768, 3001), (33, 1024, 2100), (256, 1280, 8192), (5, 1280, 70), (256, 1280, 65536)])
 def test_infonce_f32_policy_is_one_pass(ops, B, d, K):
     """The reference's OWN arithmetic (fp32; MoMA/mem_moco.py:29-49,77-100 + CrossEntropy) as one pass over the fp32 queue on the
     f32-input MFMA (infonce_f32.hip): no [B,K+1] logits (the workspace is the chunk partials), loss / lse / top-1 / dq against the
-    fp64 oracle at the fp32 tolerance of the staged path it replaces, forward-only == with-gradient, bitwise repeatable."""
+    fp64 oracle at the fp32 tolerance of the staged path it replaces, forward-only == with-gradient, bitwise repeatable.
+    d = 384 / 768 / 1024 / 1280 (the reference CLI's default --head None: d = s_dim, train_student_moma.py:101-110) stream each
+    wave's slab of a key tile through LDS in 3 / 3 / 2 / 5 segments (round 4)."""
     from moma_amd import _lib
     rng = np.random.default_rng(B + d + K)
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
@@ -354,7 +357,7 @@ def test_infonce_f32_policy_is_one_pass(ops, B, d, K):
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
     T = 0.15
     ws = _lib.load().moma_infonce_fused_workspace_bytes(B, d, K, 0, 0)
-    assert ws > 0 and (K < 65536 or ws < B * (K + 1) * 4 // 2)        # chunk partials, not a [B,K+1] logits matrix
+    assert ws > 0 and (K < 65536 or ws < B * (K + 1) * 4 // (2 if d <= 512 else 1))     # chunk partials (32 chunks x B x d fp32), not a [B,K+1] logits matrix
     ref = O.infonce_loss(O.compute_logit(q, k, queue, T, dtype=np.float64))
     ref_dq = O.infonce_grad(q, k, queue, T) * B
     tqueue = _t(queue)
@@ -376,18 +379,18 @@ def test_infonce_f32_policy_is_one_pass(ops, B, d, K):
 
 
 @pytest.mark.parametrize("scale", [30.0, 10.0])
-@pytest.mark.parametrize("d", [128, 512])
+@pytest.mark.parametrize("d", [128, 512, 384, 1280])
 def test_infonce_f32_flash_overflow_repass(ops, scale, d):
     """The fixed softmax reference of the fp32 one-pass kernel (first tile's max + 32) with a key far down the chunk that beats it
     by ~290 log2 units (scale 30: beyond the 128 of headroom -> the workgroup repeats its chunk with the true row maxima) or ~96
     (scale 10: carried by the single pass).  Guide rule 26: the rare branch gets its own forced test, full fp64 reference."""
     rng = np.random.default_rng(7)
-    B, K, T = 40, 3000, 0.15
+    B, K, T = 40, 20000, 0.15          # 625 tiles -> chunks of 5 tiles (at K = 3000 every tile opens its own chunk: no overflow possible)
     q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
     queue = O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32))
-    queue[1500] = scale * q[5] / np.linalg.norm(q[5])
-    queue[2999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])
+    queue[1500] = scale * q[5] / np.linalg.norm(q[5])                 # tile 46 = second tile of chunk 9
+    queue[19999] = (scale - 5.0) * q[17] / np.linalg.norm(q[17])      # the queue's last tile = last tile of its chunk
     ref = O.infonce_loss(O.compute_logit(q, k, queue, T, dtype=np.float64))
     ref_dq = O.infonce_grad(q, k, queue, T) * B
     tq = _t(q).requires_grad_(True)

@@ -397,14 +397,18 @@ def test_loop_cross_attention_paths_match_step_oracle(mem, attn):
     np.testing.assert_allclose(contrast.memory.cpu().numpy(), ocontrast.memory.numpy(), rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize("d,K", [(768, 8192), (1280, 16384), (2048, 8192)])
-def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
+@pytest.mark.parametrize("d,K,prec", [(768, 8192, "bf16"), (1280, 16384, "bf16"), (2048, 8192, "bf16"),
+                                      (1280, 16384, "fp32"), (384, 8192, "fp32")])
+def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K, prec):
     """Wide feature dims (the regime of the reference CLI's default `--head None`: EfficientNet-B0 -> d = 1280, ResNet-50 -> 2048) at
     LOOP level under the bf16 policy: the two-pass wide-row K2 (infonce_wide_scores_kernel -- at d = 2048 in two register passes of
     Q -- + infonce_wide_pv2_kernel, bf16 queue), K1 on the wide-head fast path (head dim 192 / 320 / 512 > 128: segment-streamed
     cores), K3, K4; teacher side on the second stream.  3 steps of
     train_distill_moma against the CPU step oracle (fp32; its pieces are pinned to the reference by G1-G5).  Tolerances as in
-    the big-queue test: first step 1e-3 relative (the kernels' own error), later steps 5e-3 (bf16 gradient rounding through SGD)."""
+    the big-queue test: first step 1e-3 relative (the kernels' own error), later steps 5e-3 (bf16 gradient rounding through SGD).
+    prec = fp32 (round 4): the same loop in the reference's own arithmetic at the reference CLI's default width -- the exact-fp32
+    one-pass K2 over the fp32 queue (infonce_f32.hip, 5 / 3 column segments per wave at d = 1280 / 384: no [B,K+1] logits), staged
+    exact-fp32 K1 -- loss_kd within 2e-5 relative on every step."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import copy
@@ -419,9 +423,14 @@ def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
     B, lr = 8, 0.002
     opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.999,
                              cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
-                             batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
+                             batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec=prec,
+                             queue_dtype="bf16" if prec == "bf16" else "fp32",
                              moma_fused=True, trace=[], overlap_teacher=True, graph_teacher=False, local_rank=0, node_rank=0,
                              ngpus_per_node=1)
+    if prec == "fp32":
+        from moma_amd import _lib
+        # the one-pass kernel takes the shape: its workspace is the chunk partials, not the staged path's [B,K+1] logits matrix
+        assert _lib.load().moma_infonce_fused_workspace_bytes(B, d, K, 0, 0) != (B * (K + 1) * 4 + 255) // 256 * 256
     torch.manual_seed(4321 + d)
     ms, mt = resnet8(num_classes=10), resnet8(num_classes=10)
     contrast = build_mem(opt)
@@ -450,12 +459,16 @@ def test_loop_wide_queue_bf16_policy_matches_step_oracle(d, K):
     ref_kd, ref_loss = np.array([r[2] for r in ref]), np.array([r[0] for r in ref])
     print("loss_kd |err|:", np.abs(kds - ref_kd).round(5), " total |err|:", np.abs(losses - ref_loss).round(5))
     assert [t[1] for t in opt.trace] == [(i + 1) * B % K for i in range(3)] and ocontrast.index == contrast.index
-    assert abs(kds[0] - ref_kd[0]) < 1e-3 * abs(ref_kd[0])
-    np.testing.assert_allclose(kds, ref_kd, rtol=5e-3, atol=5e-3)
-    np.testing.assert_allclose(losses, ref_loss, rtol=5e-3, atol=5e-3)
+    if prec == "fp32":
+        np.testing.assert_allclose(kds, ref_kd, rtol=2e-5, atol=0)
+        np.testing.assert_allclose(losses, ref_loss, rtol=5e-5, atol=0)
+    else:
+        assert abs(kds[0] - ref_kd[0]) < 1e-3 * abs(ref_kd[0])
+        np.testing.assert_allclose(kds, ref_kd, rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(losses, ref_loss, rtol=5e-3, atol=5e-3)
     rows = contrast.memory[:3 * B].float().cpu().numpy()
     ref_rows = ocontrast.memory[:3 * B].numpy()
-    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=3e-2 * np.abs(ref_rows).max())
+    np.testing.assert_allclose(rows, ref_rows, rtol=0, atol=(3e-2 if prec == "bf16" else 1e-4) * np.abs(ref_rows).max())
 
 
 def test_mlp_byol_head_runs_the_kd_term_on_the_gpu():
