@@ -151,6 +151,12 @@ struct SlabArgs {
 //   = rows 16g + 4h + {0,1 | 2,3 | 8,9 | 10,11}[w] of column 32c + (lane&31), h = lane>>5
 // (O[c][r] is query row (r&3) + 8*(r>>2) + 4*h); the combine kernel gives one workgroup the 8 rows of a (block, g, h).
 __device__ __forceinline__ int opart_row(int g, int h, int w, int u) { return 16 * g + 4 * h + 8 * (w >> 1) + 2 * (w & 1) + u; }
+// Which partials exist.  The passes over the queue skip the O partial of a wave block (32 query rows) that lies past B entirely,
+// and the combine kernel must then never read it: BOTH sides decide with these two predicates.  group_live relies on
+// opart_row(g, h, 0, 0) being the SMALLEST of the 8 rows of a (g, h) group (w, u only add), so "its first row is live" <=> "the
+// wave block that holds it was stored" -- a layout change to opart_row has to keep that, or change both predicates together.
+__device__ __forceinline__ bool wave_block_live(int wb, int B) { return wb * 32 < B; }
+__device__ __forceinline__ bool group_live(int wb, int g, int h, int B) { return wb * 32 + opart_row(g, h, 0, 0) < B; }
 
 template <int D, bool WITH_DQ, int MODE = 0>
 __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, const uint4* __restrict__ qpack,
@@ -645,7 +651,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
         // of a wave are ~5 k cycles of pure issue).  A repeat pass simply stores again.
         {
             // (a wave whose 32 rows all lie past B -- small or ragged batches -- multiplied zeros: nothing of it is read back)
-            const bool live = bt * QROWS_WG + wave * 32 < B;
+            const bool live = wave_block_live(bt * (QROWS_WG / 32) + wave, B);
             uint4* dst = opart_dst();
             pv(std::false_type{}, slot(t1 - 1), pa, [&](int) __attribute__((always_inline)) {}, [&](int c) __attribute__((always_inline)) {
                 if (c >= 1 && live) store_tile(dst, c - 1);
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
     const int t1 = min(t0 + tiles_per_chunk, ntiles);
     const DmaLane dl = dma_lane_terms<D>(lane, wave, (unsigned)(D * 2));
     const long prow = (long)chunk * Bpad + rb * 32;
-    const bool live = rb * 32 < B;
+    const bool live = wave_block_live(rb, B);
 
     // ---- Q fragments (B operand of the 16x16x32 product): lane l holds Q[32 rb + 16 m + (l&15)][32 s + 8 (l>>4) + j]
     //      = element (k-step 2s + (g>>1), lane 16m + (l&15) + 32 (g&1)) of the packed image; inline asm, counted by hand
@@ -881,85 +887,117 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
 #pragma unroll
         for (int s = 0; s < KS2; ++s) { asm volatile("" : "+v"(qf[0][s])); asm volatile("" : "+v"(qf[1][s])); }
         __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-        for (int t = t0; t < t1; ++t) {
-            const char* buf = slot(t);
-            const bool refill = t + NBUF - 1 < t1;            // tile t+3 into the slot of tile t-1 (free since the last barrier)
-            const long rkey0 = (long)(t + NBUF - 1) * KT;
-            char* rbuf = slot(t + NBUF - 1);
-            // ---- scores of this wave's 16 keys x 32 query rows.  refill_tag: 0 = no refill, 1 = a full tile, 2 = the queue's last
-            //      (partial) tile -- chosen once per tile, not per DMA piece
-            f32x4 x0, x1;
-            auto score = [&](auto refill_tag) __attribute__((always_inline)) {
-                constexpr int REFILL = decltype(refill_tag)::value;
-                {
-                    const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) aa[c] = a0 ^ (c << 6);
-#pragma unroll
-                    for (int s = 0; s < RD; ++s) rd(s);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int s = 0; s < KS2; ++s) {
-                    const int ahead = (KS2 - 1 - s) < (RD - 1) ? (KS2 - 1 - s) : (RD - 1);
-                    wait_lgkm(ahead);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // inline asm (the fragments are asm-loaded registers: nothing may copy them before the wait above); the two
-                    // accumulate chains alternate; the last MFMA carries the wait states in front of the VALU readers (8-pass: 12)
-                    if (s == 0) {
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
-                    } else if (s == KS2 - 1) {
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 11" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
-                    } else {
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + RD < KS2) rd(s + RD);
-                    if constexpr (REFILL != 0) {
-                        if ((s & 1) == 1) dma_piece<D, REFILL == 2>(s >> 1, dl, queue, rkey0, K, rbuf, wave, lane);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            if (!refill) score(std::integral_constant<int, 0>{});
-            else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{});
-            else score(std::integral_constant<int, 1>{});
-            // first transposed reads of P.K while the softmax runs
+        // ---- scores of this wave's 16 keys x 32 query rows of the tile in `buf`.  refill_tag: 0 = no refill, 1 = a full tile, 2 =
+        //      the queue's last (partial) tile into `rbuf` -- chosen once per tile, not per DMA piece
+        auto score = [&](auto refill_tag, const char* buf, long rkey0, char* rbuf, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+            constexpr int REFILL = decltype(refill_tag)::value;
             {
-                const unsigned b0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + b_off;
+                const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    ba[c4][0] = b0 ^ (c4 << 6);
-                    ba[c4][1] = b0 ^ ((c4 << 6) | 32);
-                }
+                for (int c = 0; c < 4; ++c) aa[c] = a0 ^ (c << 6);
 #pragma unroll
-                for (int c = 0; c < PF; ++c) issue_tr(c);
+                for (int s = 0; s < RD; ++s) rd(s);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- lane (q = L & 31, h): keys 4h + r (xa) and 8 + 4h + r (xb) of the wave's half
-            float xa[4], xb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0[r]), __float_as_uint(x1[r]), false, false);
-                xa[r] = __uint_as_float(sw[0]);
-                xb[r] = __uint_as_float(sw[1]);
+            for (int s = 0; s < KS2; ++s) {
+                // (older LDS requests -- the first transposed reads of P.K, issued ahead of this product -- complete first: the
+                //  counter only has to leave room for the younger row reads)
+                const int ahead = (KS2 - 1 - s) < (RD - 1) ? (KS2 - 1 - s) : (RD - 1);
+                wait_lgkm(ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                // inline asm (the fragments are asm-loaded registers: nothing may copy them before the wait above); the two
+                // accumulate chains alternate; the last MFMA carries the wait states in front of the VALU readers (8-pass: 12)
+                if (s == 0) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                } else if (s == KS2 - 1) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 11" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                } else {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x0) : "v"(kf[s % RD]), "v"(qf[0][s]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(x1) : "v"(kf[s % RD]), "v"(qf[1][s]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + RD < KS2) rd(s + RD);
+                if constexpr (REFILL != 0) {
+                    if ((s & 1) == 1) dma_piece<D, REFILL == 2>(s >> 1, dl, queue, rkey0, K, rbuf, wave, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        auto score_tile = [&](const char* buf, bool refill, int rtile, f32x4& x0, f32x4& x1) __attribute__((always_inline)) {
+            const long rkey0 = (long)rtile * KT;
+            char* rbuf = slot(rtile);
+            if (!refill) score(std::integral_constant<int, 0>{}, buf, rkey0, rbuf, x0, x1);
+            else if (rkey0 + KT > K) score(std::integral_constant<int, 2>{}, buf, rkey0, rbuf, x0, x1);
+            else score(std::integral_constant<int, 1>{}, buf, rkey0, rbuf, x0, x1);
+        };
+        // first transposed reads of P.K on the tile in `buf` (issued AHEAD of whatever hides their latency)
+        auto pv_begin = [&](const char* buf) __attribute__((always_inline)) {
+            const unsigned b0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + b_off;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                ba[c4][0] = b0 ^ (c4 << 6);
+                ba[c4][1] = b0 ^ ((c4 << 6) | 32);
+            }
+#pragma unroll
+            for (int c = 0; c < PF; ++c) issue_tr(c);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // O[q, cols] += P[q, 16 keys] . K_half[16 keys, cols]; `between(c)` runs in the shadow of column tile c's MFMA
+        auto pv = [&](const bf16x8& pa, auto&& between) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
+                wait_lgkm(2 * ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                s16x4* k2 = kb[c % (PF + 1)];
+                const s16x8 kk = __builtin_shufflevector(k2[0], k2[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, kk), O[c], 0, 0, 0);
+                if (c + PF < NCT) issue_tr(c + PF);
+                between(c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // lane (q = L & 31, h) after the swaps: keys 4h + r (e[r]) and 8 + 4h + r (e[4 + r]) of the wave's half
+        auto swap_pair = [&](const f32x4& x0, const f32x4& x1, int r, float (&e)[8]) __attribute__((always_inline)) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0[r]), __float_as_uint(x1[r]), false, false);
+            e[r] = __uint_as_float(sw[0]);
+            e[4 + r] = __uint_as_float(sw[1]);
+        };
+        auto mask_tail = [&](float (&e)[8], int t) __attribute__((always_inline)) {
             if ((t + 1) * KT > K) {                           // keys past K (the queue's last tile)
                 const int kbase = t * KT + 16 * kh + 4 * h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (kbase + r >= K) xa[r] = NEG_BIG;
-                    if (kbase + 8 + r >= K) xb[r] = NEG_BIG;
+                    if (kbase + r >= K) e[r] = NEG_BIG;
+                    if (kbase + 8 + r >= K) e[4 + r] = NEG_BIG;
                 }
             }
-            float tmax = fmaxf(fmaxf(fmaxf(xa[0], xa[1]), fmaxf(xa[2], xa[3])), fmaxf(fmaxf(xb[0], xb[1]), fmaxf(xb[2], xb[3])));
+        };
+        auto pack8 = [&](const float (&e)[8]) __attribute__((always_inline)) -> bf16x8 {
+            return bf16x8{(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3], (__bf16)e[4], (__bf16)e[5], (__bf16)e[6], (__bf16)e[7]};
+        };
+
+        // ---- software pipeline (one wave per SIMD: nothing else hides the softmax):
+        //   prologue     X(t0), softmax all at once (fixes the shared reference of the two key halves)
+        //   iteration t  X(t+1) = scores of tile t+1 [DMA pieces of tile t+3 in its shadow]
+        //                O += P(t) . K(t)   ||   P(t+1) = softmax numerators of X(t+1), one value per column tile's MFMA
+        //   epilogue     O += P(t1-1) . K(t1-1)
+        // Live ring slots: t, t+1; in flight: t+2, t+3 (tile t+3 goes into the slot of tile t-1, free since the last barrier).
+        f32x4 x0, x1;
+        float e[8];
+        bf16x8 pa;
+        score_tile(slot(t0), false, t0, x0, x1);
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swap_pair(x0, x1, r, e);
+            mask_tail(e, t0);
+            float tmax = fmaxf(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])), fmaxf(fmaxf(e[4], e[5]), fmaxf(e[6], e[7])));
             tmax = fmaxf(tmax, other_half(tmax));
             mx = fmaxf(mx, tmax);
-            if (!repass && t == t0) {
+            if constexpr (!repass) {
                 // the two key halves of a row block share ONE fixed reference (the 32-key tile's row maximum + the margin, as the
                 // one-pass kernel): their O partials then add up without rescaling when the halves are merged behind the loop
                 // (inline asm + raw barrier: __syncthreads() would drain vmcnt, i.e. wait for the whole tile ring)
@@ -972,31 +1010,54 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
             ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xa[r] = __builtin_amdgcn_exp2f(xa[r] - m_ref);
-                xb[r] = __builtin_amdgcn_exp2f(xb[r] - m_ref);
-                psum += xa[r] + xb[r];
+            for (int r = 0; r < 8; ++r) {
+                e[r] = __builtin_amdgcn_exp2f(e[r] - m_ref);
+                psum += e[r];
             }
             l_run += psum;
-            const bf16x8 pa = bf16x8{(__bf16)xa[0], (__bf16)xa[1], (__bf16)xa[2], (__bf16)xa[3],
-                                     (__bf16)xb[0], (__bf16)xb[1], (__bf16)xb[2], (__bf16)xb[3]};
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- O[q, cols] += P[q, 16 keys] . K_half[16 keys, cols]
+            pa = pack8(e);
+        }
+        // tile t0+1 must have landed before the loop's first score (t0+2 may stay in flight)
+        wait_tiles_in_flight(max(min(t0 + 2, t1 - 1) - (t0 + 1), 0));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int t = t0; t < t1 - 1; ++t) {
+            pv_begin(slot(t));                                // (older than every read of the score product below)
+            score_tile(slot(t + 1), t + NBUF - 1 < t1, t + NBUF - 1, x0, x1);
+            float tmax = NEG_BIG, psum = 0.f;
+            pv(pa, [&](int c) __attribute__((always_inline)) {
+                // the softmax of tile t+1 in the shadows of P.K(t): the swaps behind the first two MFMAs (the score product's last
+                // MFMA already carries the wait states its readers need), then one value per column tile
+                if (c == 0) { swap_pair(x0, x1, 0, e); swap_pair(x0, x1, 1, e); }
+                if (c == 1) { swap_pair(x0, x1, 2, e); swap_pair(x0, x1, 3, e); mask_tail(e, t + 1); }
+                if (c >= 2 && c < 10 && c - 2 < 8) {
+                    const int r = c - 2;
+                    tmax = fmaxf(tmax, e[r]);
+                    e[r] = __builtin_amdgcn_exp2f(e[r] - m_ref);
+                    psum += e[r];
+                }
+            });
+            if constexpr (NCT < 10) {                         // narrow rows: fewer column tiles than softmax steps
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const int ahead = (NCT - 1 - c) < (PF - 1) ? (NCT - 1 - c) : (PF - 1);
-                wait_lgkm(2 * ahead);
-                __builtin_amdgcn_sched_barrier(0);
-                s16x4* k2 = kb[c % (PF + 1)];
-                const s16x8 kk = __builtin_shufflevector(k2[0], k2[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, kk), O[c], 0, 0, 0);
-                if (c + PF < NCT) issue_tr(c + PF);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = (NCT > 2 ? NCT - 2 : 0); r < 8; ++r) {
+                    if (NCT <= 1 && r == 0) { swap_pair(x0, x1, 2, e); swap_pair(x0, x1, 3, e); mask_tail(e, t + 1); }
+                    tmax = fmaxf(tmax, e[r]);
+                    e[r] = __builtin_amdgcn_exp2f(e[r] - m_ref);
+                    psum += e[r];
+                }
             }
-            // tile t+1 must have landed (t+2, t+3 may stay in flight); every wave is done with this slot
-            wait_tiles_in_flight(max(min(t + NBUF - 1, t1 - 1) - (t + 1), 0));
+            // tile t+2 must have landed (t+3 may stay in flight); every wave is done with slot t
+            if (t + NBUF - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            }
+            tmax = fmaxf(tmax, other_half(tmax));
+            mx = fmaxf(mx, tmax);
+            ovf |= (tmax - m_ref > OVERFLOW_THR) ? 1 : 0;
+            l_run += psum;
+            pa = pack8(e);
+        }
+        pv_begin(slot(t1 - 1));
+        pv(pa, [&](int) __attribute__((always_inline)) {});
     };
     run_pass(std::false_type{});
     {
@@ -1718,7 +1779,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
     __shared__ float rowc[8][2];                     // per row: 1/L, p0/L - 1
     const int tid = threadIdx.x;
     const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;
-    if (wb * 32 + opart_row(g, h, 0, 0) >= B) return;                    // all 8 rows of this block lie past B (pad rows: their
+    if (!group_live(wb, g, h, B)) return;                                // all 8 rows of this block lie past B (pad rows: their
                                                                          // partials are not even written by the passes over the queue)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     auto row_of = [&](int i) { return wb * 32 + opart_row(g, h, i >> 1, i & 1); };

@@ -55,6 +55,9 @@ class GraphedInference:
             if len(self._seen) < 64 or key in self._seen:
                 self._seen[key] = n
             if n <= self.warmup or len(self._graphs) >= self.max_graphs:
+                if n > self.warmup and not getattr(self, "_cap_notice", False):
+                    self._cap_notice = True
+                    print(f"[moma] GraphedInference: {self.max_graphs} variants captured (each per stream); further variants stay eager")
                 return self._trim(self.module(x, is_feat=is_feat), is_feat)
             entry = self._capture(key, x, is_feat)
             if entry is None:
@@ -75,6 +78,11 @@ class GraphedInference:
         them (seen: a variant captured on the main stream and replayed on the side stream next to the student forward
         returned garbage logits)."""
         if not (self.enabled and x.is_cuda):
+            return False
+        if any(m.training for m in self._mods if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
+            # priming serves warmup + 1 real forwards: in training mode each of them moves the running statistics
+            print("[moma] GraphedInference.prime: a BatchNorm layer is in training mode -- priming would advance its running "
+                  "statistics; variant left to the regular warm-up")
             return False
         with torch.no_grad():
             for _ in range(self.warmup + 1):

@@ -93,6 +93,7 @@ def _timed(name):
     return _EVENT_RECORDER(name)
 
 
+_DEBUG = __import__("os").environ.get("MOMA_DEBUG", "0") == "1"
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # the handle without building a Stream object
 
 
@@ -242,7 +243,12 @@ class QPack:
     """The query of K2 in the packed bf16 MFMA-operand layout (moma_infonce_fused_q), written by the producer of q -- the proj
     epilogue of the attention module atts_q (moma_mha_fwd_fast) -- so that K2 runs no pre-pack launch.  One persistent buffer
     per (B, d): its pad rows stay zero.  `src` remembers which q tensor / temperature the image was made from; K2 ignores
-    the image unless it is handed exactly that tensor."""
+    the image unless it is handed exactly that tensor.
+    Caveat (as for the weight packs, Attention.invalidate_pack): the identity check is (data_ptr, autograd version, shape, T).  A
+    write to q that bypasses the version counter -- arithmetic on `q.data`, a raw-pointer kernel -- between the producer and K2
+    leaves a stale image that K2 would pair with the new fp32 q (positive logit and dq come from the fp32 tensor).  Nothing in
+    the loop does that; a caller that does must drop the image (`qpack.src = None`) or pass `qpack=None` to K2.  MOMA_DEBUG=1
+    re-packs q inside infonce_fused and compares (a test hook, costs a launch and a sync)."""
 
     def __init__(self):
         self.buf, self.shape, self.scale, self.src = None, None, None, None
@@ -361,6 +367,13 @@ def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = No
     if qpack is not None and q.is_contiguous() and qpack.matches(q, T) and queue.dtype == torch.bfloat16 \
             and prec_code(prec) == PREC_BF16:
         buf = qpack.buf
+        if _DEBUG:
+            # the image K2 is about to trust against one made from q as it stands now (own pre-pack: a forward-only call without it)
+            with torch.no_grad():
+                a = _InfoNCEFused.apply(q.detach(), k.detach(), queue, float(T), prec_code(prec), buf)[1]
+                b = _InfoNCEFused.apply(q.detach(), k.detach(), queue, float(T), prec_code(prec), None)[1]
+            if not torch.equal(a, b):
+                raise MomaHipError("QPack: the packed image of q does not match q (written behind autograd's version counter?)")
     return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec), buf)
 
 

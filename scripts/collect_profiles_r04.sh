@@ -3,13 +3,13 @@
 #   K1: HBM / fabric traffic and L2 hit counters next to the SQ counters (the "cold L2" model of DESIGN.md, VERDICT r3 #6a)
 #   K2 wide rows: SQ + FETCH / WRITE passes for d = 1280 and d = 2048 (none existed for 2048; 1280 was round 2's)
 #   K2 small batch (B = 64: the reference's default --batch_size): kernel stats + SQ + FETCH / WRITE
-#   the training step under the step graphs
-# usage (GPU box, repo root):  bash scripts/collect_profiles_r04.sh [sections]      sections: k1 k2w k2x k2s step   (default: all)
+#   K2 exact-fp32 at d = 1280 (the segment-streamed one-pass kernel); the training step under the step graphs (B = 256 and 64)
+# usage (GPU box, repo root):  bash scripts/collect_profiles_r04.sh [sections]      sections: k1 k2 k2w k2x k2s k2f step step64   (default: all)
 TAG=r04
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-SECT=${1:-"k1 k2w k2x k2s step"}
+SECT=${1:-"k1 k2 k2w k2x k2s k2f step step64"}
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"
 prof() { d=$1; shift; rm -rf $O/$d; timeout -k 10 300 rocprofv3 "$@" > $O/$d.log 2>&1 || echo "FAILED: $d"; echo "done $d"; }
@@ -53,6 +53,16 @@ k2)
   pmc3 k2 $K2
   cd $R; python scripts/summarise_profiles.py ${TAG}_k2 $O/k2
   python scripts/summarise_pmc.py profiles/${TAG}_k2_pmc.csv $O/k2_sq $O/k2_fetch $O/k2_write $O/k2_tcc; cd /tmp ;;
+k2f)
+  KF="python3 $R/scripts/bench_k2_f32.py 256 1280 65536"
+  prof k2f --kernel-trace --stats -d $O/k2f --output-format csv -- $KF
+  prof k2f_sq --pmc $SQ -d $O/k2f_sq --output-format csv -- $KF
+  prof k2f_fetch --pmc FETCH_SIZE -d $O/k2f_fetch --output-format csv -- $KF
+  cd $R; python scripts/summarise_profiles.py ${TAG}_k2_f32_d1280 $O/k2f
+  python scripts/summarise_pmc.py profiles/${TAG}_k2_f32_d1280_pmc.csv $O/k2f_sq $O/k2f_fetch; cd /tmp ;;
+step64)
+  prof step64 --kernel-trace --stats -d $O/step64 --output-format csv -- python3 $R/bench.py --steps 10 --warmup 5 --no_cpu_baseline --batch_size 64
+  cd $R; python scripts/summarise_profiles.py ${TAG}_step_b64 $O/step64; cd /tmp ;;
 step)
   prof step --kernel-trace --stats -d $O/step --output-format csv -- python3 $R/bench.py --steps 10 --warmup 5 --no_cpu_baseline
   cd $R; python scripts/summarise_profiles.py ${TAG}_step $O/step; cd /tmp ;;
