@@ -36,6 +36,7 @@ import torch.nn as nn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3    # f32-input MFMA (= the fp32 vector rate; MI355X_MICROARCH.md)
 
 
 def parse():
@@ -486,7 +487,13 @@ def main():
         bytes_, flops = k2_algorithmic(a.batch_size, d, a.nce_k, qbytes)
         # governing bound = the larger ideal time: HBM for a 4-byte queue, MFMA for bf16 at B=256
         t_hbm, t_mfma = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
-        if a.moma_prec == "bf16" and t_mfma > t_hbm:
+        if a.moma_prec == "fp32":
+            # exact-fp32 policy: the f32-input MFMA (an exact fp32 fma chain) runs at the fp32 vector rate, 1/16 of the bf16 rate --
+            # that rate, not HBM, bounds the one-pass kernel (34.4 GFLOP -> 219 us at d = 512 against 17 us for its 135 MB)
+            ach = flops / (k2_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}
+        elif a.moma_prec == "bf16" and t_mfma > t_hbm:
             ach = flops / (k2_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
@@ -517,7 +524,10 @@ def main():
                                              "call (3 launches each; atts_k + atts_queue run as ONE group of 3 launches on the side stream); "
                                              "in-kernel matrix-pipe shares are in pmc.k1_*"}
         roof["other"] = other
-        kname = (("infonce_small_kernel (K2 one pass over the queue, key-half split for B <= 64; moma_infonce_fused)" if a.batch_size <= 64 else
+        kname = ("infonce_f32_flash_kernel (K2 one pass over the fp32 queue on the f32-input MFMA; moma_infonce_fused)"
+                 if (a.moma_prec == "fp32" and a.queue_dtype == "fp32" and d in (128, 256, 384, 512, 768, 1024, 1280)) else
+                 "staged exact-fp32 K2 (logits -> row reduction -> gradient GEMM)" if a.moma_prec == "fp32" else
+                 ("infonce_small_kernel (K2 one pass over the queue, key-half split for B <= 64; moma_infonce_fused)" if a.batch_size <= 64 else
                   "infonce_flash_kernel (K2 one pass over the queue; moma_infonce_fused)") if d <= 512 else
                  "infonce_wide_scores_kernel + infonce_wide_pv2_kernel (K2 over a wide queue, d > 512: the two passes over the queue; "
                  "like the one-pass line the Q pre-pack in front and the combine behind are in whole_call_ms only)")
@@ -529,7 +539,7 @@ def main():
                                         "_between_host_events adds the latency of two event packets recorded around the C-ABI call",
                      "algorithmic_bytes": bytes_, "algorithmic_flops": flops,
                      "hbm_frac": round(bytes_ / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "mfma_frac": round(flops / (k2_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "mfma_frac": round(flops / (k2_ms * 1e-3) / 1e12 / (MFMA_F32_PEAK_TFLOPS if a.moma_prec == "fp32" else MFMA_BF16_PEAK_TFLOPS), 4),
                      "other_ms": {k: round(rec.mean_ms(k), 4) for k in rec.events if k != "moma_infonce_fused"}})
         out = {
             "metric": "images/sec MoMA train step (EffNet-B0 224px, K=65536)",
