@@ -18,6 +18,7 @@
 // log-sum-exp, flash-style) -> {dWqkv, dbqkv, dx}: 3 launches.  No atomics: every output is one fixed-order sum.
 #include "common.hpp"
 #include <mutex>
+#include <type_traits>
 
 namespace moma {
 namespace {
@@ -594,11 +595,14 @@ __global__ __launch_bounds__(NW * 64) void k1_core_fwd_kernel(CoreFwdArgs a) {
 }
 
 
-// ---- wide heads (128 < head dim, e.g. `--head None` on EfficientNet-B0: d = 1280, 4 heads of 320), N <= 32 * NW -----------------
-// The products are separable over 128-column SEGMENTS of the head: S = sum_seg Q_seg K_seg^T, O_seg = P V_seg.  One key tile per
-// wave as in the ONE_TILE kernel; the segment images stream through the same two 8 KiB images per wave (and the one Q image of
-// the workgroup), so the LDS budget does not grow with the head dim: phase 1 accumulates the scores over the segments, the row
-// statistics follow, phase 2 forms one segment of O at a time (4 accumulator tiles) and sums it over the waves through LDS.
+// ---- wide heads (128 < head dim, e.g. `--head None` on EfficientNet-B0: d = 1280, 4 heads of 320), N <= 32 * NW * TW ------------
+// The products are separable over 128-column SEGMENTS of the head: S = sum_seg Q_seg K_seg^T, O_seg = P V_seg.  Every wave owns up
+// to TW key tiles (tiles wave, wave + NW, ...: TW = 1 up to N = 256, 2 up to 512, 4 up to 1024 -- the concatenated [q ; k] token
+// sets of the MoCoAtt variants) and keeps their score tiles in registers; the segment images stream through the same two 8 KiB
+// images per wave (and the one Q image of the workgroup), so the LDS budget grows neither with the head dim nor with N: phase 1
+// accumulates the scores of the wave's tiles over the segments, the row statistics follow, phase 2 forms one segment of O at a
+// time (4 accumulator tiles, summed over the wave's tiles) and sums it over the waves through LDS.
+template <int TW>
 __global__ __launch_bounds__(NW * 64) void k1_core_fwd_wide_kernel(CoreFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const CoreMod M = a.m[blockIdx.z];
@@ -617,39 +621,60 @@ __global__ __launch_bounds__(NW * 64) void k1_core_fwd_wide_kernel(CoreFwdArgs a
     char* imgV = imgK + 8192;
     float* s_ml = reinterpret_cast<float*>(smem + 8192 + NW * 16384);
     const unsigned boff = tr_lane_offset(lane);
+    // the wave's tile j covers keys [(wave + NW j) KT, +KT); its images alternate between the wave's two buffers so that the next
+    // tile's DMA runs under this tile's MFMAs (8 pieces per tile image: "all but the newest tile landed" = vmcnt(8))
+    auto tile_row0 = [&](int j) { return (wave + NW * j) * KT; };
+    auto wait_newest_in_flight = [&](bool more) __attribute__((always_inline)) {
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 
-    // ---- phase 1: the wave's score tile, accumulated over the segments (V's first segment rides along)
-    f32x16 x;
+    // ---- phase 1: the wave's score tiles, accumulated over the segments
+    f32x16 x[TW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = 0.f;
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[j][r] = 0.f;
     for (int sg = 0; sg < nseg; ++sg) {
         const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, kse = w >> 4;
         if (sg) __syncthreads();                                 // every wave is done with the previous Q image
         dma_piece(qb, ld, q0, N, c0, nch, imgQ, wave, lane);
-        dma_tile32(kb, ld, wave * KT, N, c0, nch, imgK, lane);
-        if (sg == 0) dma_tile32(vb, ld, wave * KT, N, 0, nch, imgV, lane);
-        wait_dma();
-        __syncthreads();
+        dma_tile32(kb, ld, tile_row0(0), N, c0, nch, imgK, lane);
+        if (TW == 1 && sg == 0) dma_tile32(vb, ld, tile_row0(0), N, 0, nch, imgV, lane);      // (one tile: V's first segment rides along)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (ks < kse) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(imgK, n, h2, ks), row_frag(imgQ, n, h2, ks), x, 0, 0, 0);
-        asm volatile("" ::: "memory");
-    }
-    if ((wave + 1) * KT > N) {
+        for (int j = 0; j < TW; ++j) {
+            char* img = (j & 1) ? imgV : imgK;
+            if (j + 1 < TW) dma_tile32(kb, ld, tile_row0(j + 1), N, c0, nch, (j & 1) ? imgK : imgV, lane);
+            wait_newest_in_flight(j + 1 < TW);
+            if (j == 0) __syncthreads();                         // the Q image is complete
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (wave * KT + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) x[r] = NEG_BIG;
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < kse) x[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img, n, h2, ks), row_frag(imgQ, n, h2, ks), x[j], 0, 0, 0);
+            asm volatile("" ::: "memory");
+        }
     }
-    // ---- the row log-sum-exp over the waves' tiles
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+        if (tile_row0(j) + KT > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tile_row0(j) + (r & 3) + 8 * (r >> 2) + 4 * h2 >= N) x[j][r] = NEG_BIG;
+        }
+    }
+    // ---- the row log-sum-exp over all tiles of all waves
     float lse2;
     {
-        float tmax = x[0];
+        float tmax = NEG_BIG;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, x[r]);
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[j][r]);
         tmax = fmaxf(tmax, other_half(tmax));
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(x[r] - tmax);
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(x[j][r] - tmax);
         ps += other_half(ps);
         if (h2 == 0) {
             s_ml[(wave * 32 + n) * 2 + 0] = tmax;
@@ -665,31 +690,40 @@ __global__ __launch_bounds__(NW * 64) void k1_core_fwd_wide_kernel(CoreFwdArgs a
         lse2 = mm + __builtin_amdgcn_logf(ll);                   // v_log_f32 = log2
     }
     if (M.lse != nullptr && wave == 0 && h2 == 0 && q0 + n < N) M.lse[(long)head * N + q0 + n] = lse2;
+    bf16x8 pa[TW][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r] - lse2);
-    const bf16x8 pa0 = tile_as_a(x, 0), pa1 = tile_as_a(x, 1);
+    for (int j = 0; j < TW; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[j][r] = __builtin_amdgcn_exp2f(x[j][r] - lse2);
+        pa[j][0] = tile_as_a(x[j], 0);
+        pa[j][1] = tile_as_a(x[j], 1);
+    }
 
-    // ---- phase 2: O_seg = sum over the waves of P . V_seg
+    // ---- phase 2: O_seg = sum over the waves (and their tiles) of P . V_seg
     float* s_o = reinterpret_cast<float*>(smem + 8192);
     for (int sg = 0; sg < nseg; ++sg) {
         const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, nct = (w + 31) >> 5;
-        if (sg) {
-            dma_tile32(vb, ld, wave * KT, N, c0, nch, imgV, lane);
-            wait_dma();
-        }
         f32x16 O[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
-        const unsigned vl = lds_addr(imgV);
+        if (TW > 1 || sg) dma_tile32(vb, ld, tile_row0(0), N, c0, nch, imgV, lane);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 vf[4];
-            tr_frags4(vl, boff, s, vf);
+        for (int j = 0; j < TW; ++j) {
+            char* img = (j & 1) ? imgK : imgV;
+            if (j + 1 < TW) dma_tile32(vb, ld, tile_row0(j + 1), N, c0, nch, (j & 1) ? imgV : imgK, lane);
+            wait_newest_in_flight(j + 1 < TW);
+            const unsigned vl = lds_addr(img);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < nct) O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? pa0 : pa1, vf[c], O[c], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 vf[4];
+                tr_frags4(vl, boff, s, vf);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < nct) O[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[j][s], vf[c], O[c], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
         }
         // the wave's slice (its own two images: consumed) takes its partial; O[c][r] = query (r&3)+8(r>>2)+4h2, column 32c+n
 #pragma unroll
@@ -912,10 +946,13 @@ __global__ __launch_bounds__(NW * 64) void k1_core_bwd_kernel(CoreBwdArgs a) {
 }
 
 
-// ---- wide heads, backward: the same two roles with the head's columns in 128-column segments and one reduction tile per wave
-// (N <= 32 * NW).  Phase 1: X and S accumulate over the segments (the block images and the wave's tile images are re-filled per
-// segment); P and dS follow once; phase 2 forms one segment of dQ (or dK and dV) at a time and sums it over the waves.
-template <bool ROLE_KV>
+// ---- wide heads, backward: the same two roles with the head's columns in 128-column segments and up to TW reduction tiles per
+// wave (N <= 32 * NW * TW).  Phase 1: X and S of every tile of the wave accumulate over the segments (the block images and the
+// wave's tile images are re-filled per segment and tile); P and dS follow once per tile; phase 2 forms one segment of dQ (or dK
+// and dV) at a time, summed over the wave's tiles in registers and over the waves through LDS.
+template <int TW> constexpr int bwd_wide_lds() { return 2 * 8192 + NW * 16384 + NW * 256 * TW; }
+
+template <bool ROLE_KV, int TW>
 __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdArgs& a) {
     const int N = a.N, d = a.d, hd = d / a.H;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -935,9 +972,9 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
     char* imgS = smem + 8192;               // ROLE_Q: Qs_blk ; ROLE_KV: K_blk   (B operand of S)
     char* img1 = smem + 16384 + wave * 16384;   // ROLE_Q: V_t ; ROLE_KV: dA_t
     char* img2 = img1 + 8192;                   // ROLE_Q: K_t ; ROLE_KV: Qs_t
-    float* sLD = reinterpret_cast<float*>(smem + 16384 + NW * 16384) + wave * 64;    // [32] lse | [32] D of the tile rows
+    float* sLD = reinterpret_cast<float*>(smem + 16384 + NW * 16384) + wave * 64 * TW;   // per tile: [32] lse | [32] D of the tile rows
     const unsigned boff = tr_lane_offset(lane);
-    const int t0 = wave * KT;
+    auto tile_row0 = [&](int j) { return (wave + NW * j) * KT; };
     const bool lane_ok = b0 + n < N;
     float Ln = 0.f, Dn = 0.f;
     if (!ROLE_KV && lane_ok) {
@@ -945,119 +982,143 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
         for (int i = 0; i < npart; ++i) Dn += Dp[(long)i * N + b0 + n];
     }
     if (ROLE_KV && h2 == 0) {
-        const int q = min(t0 + n, N - 1);
-        float dsum = 0.f;
-        for (int i = 0; i < npart; ++i) dsum += Dp[(long)i * N + q];
-        sLD[n] = Lh[q];
-        sLD[32 + n] = dsum;
-    }
-    f32x16 x, sc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = 0.f; sc[r] = 0.f; }
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, kse = w >> 4;
-        if (sg) __syncthreads();                                 // every wave is done with the previous block images
-        if constexpr (!ROLE_KV) {
-            dma_piece(dab, d, b0, N, c0, nch, imgR, wave, lane);
-            dma_piece(qb, ld, b0, N, c0, nch, imgS, wave, lane);
-            dma_tile32(vb, ld, t0, N, c0, nch, img1, lane);
-            dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
-        } else {
-            dma_piece(vb, ld, b0, N, c0, nch, imgR, wave, lane);
-            dma_piece(kb, ld, b0, N, c0, nch, imgS, wave, lane);
-            dma_tile32(dab, d, t0, N, c0, nch, img1, lane);
-            dma_tile32(qb, ld, t0, N, c0, nch, img2, lane);
-        }
-        wait_dma();
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (ks < kse) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img1, n, h2, ks), row_frag(imgR, n, h2, ks), x, 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (ks < kse) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img2, n, h2, ks), row_frag(imgS, n, h2, ks), sc, 0, 0, 0);
-        asm volatile("" ::: "memory");
-    }
-    f32x16 p, ds;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 l4, d4;
-        if constexpr (ROLE_KV) {
-            l4 = *reinterpret_cast<const float4*>(&sLD[8 * g + 4 * h2]);
-            d4 = *reinterpret_cast<const float4*>(&sLD[32 + 8 * g + 4 * h2]);
-        } else {
-            l4 = make_float4(Ln, Ln, Ln, Ln);
-            d4 = make_float4(Dn, Dn, Dn, Dn);
-        }
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * g + i;
-            const int tr = t0 + 8 * g + 4 * h2 + i;
-            const float pv = __builtin_amdgcn_exp2f(sc[r] - lv[i]);
-            p[r] = (tr < N && lane_ok) ? pv : 0.f;
-            ds[r] = p[r] * (x[r] - dv[i]) * (ROLE_KV ? 0.6931471805599453f : scale);
+        for (int j = 0; j < TW; ++j) {
+            const int q = min(tile_row0(j) + n, N - 1);
+            float dsum = 0.f;
+            for (int i = 0; i < npart; ++i) dsum += Dp[(long)i * N + q];
+            sLD[j * 64 + n] = Lh[q];
+            sLD[j * 64 + 32 + n] = dsum;
         }
     }
-    const bf16x8 dsa0 = tile_as_a(ds, 0), dsa1 = tile_as_a(ds, 1);
-    const bf16x8 pa0 = tile_as_a(p, 0), pa1 = tile_as_a(p, 1);
+    // Phase 1 ONE TILE AT A TIME: the X and S tiles of the tile in work live in registers across the segments (2 x 16 registers),
+    // its P / dS fragments (16 registers per tile) are what persists -- with the X and S of two or more tiles alive at once (plus
+    // the row fragments hipcc requests ahead) three and four tiles per wave spill.  The block images are re-filled per tile and
+    // segment (L2 hits).
+    constexpr int GP = 1;
+    bf16x8 dsa[TW][2], pa[TW][2];
+#pragma unroll
+    for (int g0 = 0; g0 < TW; g0 += GP) {
+        f32x16 x[GP], sc[GP];
+#pragma unroll
+        for (int jj = 0; jj < GP; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[jj][r] = 0.f; sc[jj][r] = 0.f; }
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, kse = w >> 4;
+            if (sg || g0) __syncthreads();                       // every wave is done with the previous block images
+            if constexpr (!ROLE_KV) {
+                dma_piece(dab, d, b0, N, c0, nch, imgR, wave, lane);
+                dma_piece(qb, ld, b0, N, c0, nch, imgS, wave, lane);
+            } else {
+                dma_piece(vb, ld, b0, N, c0, nch, imgR, wave, lane);
+                dma_piece(kb, ld, b0, N, c0, nch, imgS, wave, lane);
+            }
+#pragma unroll
+            for (int jj = 0; jj < GP; ++jj) {
+                if (g0 + jj < TW) {
+                    const int t0 = tile_row0(g0 + jj);
+                    if constexpr (!ROLE_KV) {
+                        dma_tile32(vb, ld, t0, N, c0, nch, img1, lane);
+                        dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
+                    } else {
+                        dma_tile32(dab, d, t0, N, c0, nch, img1, lane);
+                        dma_tile32(qb, ld, t0, N, c0, nch, img2, lane);
+                    }
+                    wait_dma();
+                    if (jj == 0) __syncthreads();                // the block images are complete
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        if (ks < kse) x[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img1, n, h2, ks), row_frag(imgR, n, h2, ks), x[jj], 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        if (ks < kse) sc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(img2, n, h2, ks), row_frag(imgS, n, h2, ks), sc[jj], 0, 0, 0);
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < GP; ++jj) {
+            if (g0 + jj < TW) {
+                const int j = g0 + jj;
+                const int t0 = tile_row0(j);
+                f32x16 p, ds;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 l4, d4;
+                    if constexpr (ROLE_KV) {
+                        l4 = *reinterpret_cast<const float4*>(&sLD[j * 64 + 8 * g + 4 * h2]);
+                        d4 = *reinterpret_cast<const float4*>(&sLD[j * 64 + 32 + 8 * g + 4 * h2]);
+                    } else {
+                        l4 = make_float4(Ln, Ln, Ln, Ln);
+                        d4 = make_float4(Dn, Dn, Dn, Dn);
+                    }
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const int tr = t0 + 8 * g + 4 * h2 + i;
+                        const float pv = __builtin_amdgcn_exp2f(sc[jj][r] - lv[i]);
+                        p[r] = (tr < N && lane_ok) ? pv : 0.f;
+                        ds[r] = p[r] * (x[jj][r] - dv[i]) * (ROLE_KV ? 0.6931471805599453f : scale);
+                    }
+                }
+                dsa[j][0] = tile_as_a(ds, 0); dsa[j][1] = tile_as_a(ds, 1);
+                pa[j][0] = tile_as_a(p, 0); pa[j][1] = tile_as_a(p, 1);
+            }
+        }
+    }
     float* s_o = reinterpret_cast<float*>(smem + 16384);
     __syncthreads();
-    for (int sg = nseg - 1; sg >= 0; --sg) {                     // (the last segment's tile images are still in place: it goes first)
+    // One sweep over the wave's tiles per output (dQ; dV, then dK): ONE set of four accumulator tiles is live at a time (with dV
+    // and dK side by side two or more tiles per wave spill).  `which`: 0 = dQ (ROLE_Q), 1 = dV, 2 = dK (ROLE_KV).
+    auto sweep = [&](int sg, auto which_tag) __attribute__((always_inline)) {
+        constexpr int WHICH = decltype(which_tag)::value;
         const int c0 = sg * 128, w = min(128, hd - c0), nch = w >> 3, nct = (w + 31) >> 5;
-        if (sg != nseg - 1) {
-            if constexpr (!ROLE_KV) {
-                dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
-            } else {
-                dma_tile32(dab, d, t0, N, c0, nch, img1, lane);
-                dma_tile32(qb, ld, t0, N, c0, nch, img2, lane);
-            }
-            wait_dma();
-        }
-        f32x16 acc0[4], acc1[4];
+        f32x16 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
-        if constexpr (!ROLE_KV) {
-            const unsigned kl = lds_addr(img2);                 // dQ_seg = dS . K_t,seg
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int t0 = tile_row0(j);
+            char* img = WHICH == 1 ? img1 : img2;                 // dV reads dA_t; dQ reads K_t; dK reads Qs_t
+            // (one tile per wave: the last segment's images of phase 1 are still in place -- until the first reduction of this
+            //  role has used the waves' image slices for its partial sums: the dK sweep always fetches)
+            if (TW > 1 || sg != nseg - 1 || WHICH == 2) {
+                dma_tile32(WHICH == 0 ? kb : (WHICH == 1 ? dab : qb), WHICH == 1 ? (long)d : ld, t0, N, c0, nch, img, lane);
+                wait_dma();
+            }
+            const unsigned il = lds_addr(img);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 f[4];
-                tr_frags4(kl, boff, s, f);
+                tr_frags4(il, boff, s, f);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c < nct) acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? dsa0 : dsa1, f[c], acc0[c], 0, 0, 0);
+                    if (c < nct) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WHICH == 1 ? pa[j][s] : dsa[j][s], f[c], acc[c], 0, 0, 0);
             }
-            reduce_store16(s_o, acc0, a.dqkv + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
+            asm volatile("" ::: "memory");
+        }
+        bf16_raw* out = a.dqkv + (WHICH == 0 ? 0 : (WHICH == 2 ? d : 2 * d)) + head * hd + c0;
+        reduce_store16(s_o, acc, out, ld, b0, N, w, tid, wave, n, h2);
+    };
+    for (int sg = nseg - 1; sg >= 0; --sg) {
+        if constexpr (!ROLE_KV) {
+            sweep(sg, std::integral_constant<int, 0>{});          // dQ_seg = sum_t dS . K_t,seg
         } else {
-            const unsigned al = lds_addr(img1), ql = lds_addr(img2);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {                        // dV_seg = P' . dA_t,seg
-                bf16x8 f[4];
-                tr_frags4(al, boff, s, f);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < nct) acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? pa0 : pa1, f[c], acc1[c], 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {                        // dK_seg = dS' . Qs_t,seg  (ln 2 folded into dS')
-                bf16x8 f[4];
-                tr_frags4(ql, boff, s, f);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < nct) acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? dsa0 : dsa1, f[c], acc0[c], 0, 0, 0);
-            }
-            reduce_store16(s_o, acc0, a.dqkv + d + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
-            reduce_store16(s_o, acc1, a.dqkv + 2 * d + head * hd + c0, ld, b0, N, w, tid, wave, n, h2);
+            sweep(sg, std::integral_constant<int, 1>{});          // dV_seg = sum_t P' . dA_t,seg
+            sweep(sg, std::integral_constant<int, 2>{});          // dK_seg = sum_t dS' . Qs_t,seg  (ln 2 folded into dS')
         }
     }
 }
 
+template <int TW>
 __global__ __launch_bounds__(NW * 64) void k1_core_bwd_wide_kernel(CoreBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.z == 0) k1_core_bwd_wide_role<false>(smem, a);
-    else k1_core_bwd_wide_role<true>(smem, a);
+    if (blockIdx.z == 0) k1_core_bwd_wide_role<false, TW>(smem, a);
+    else k1_core_bwd_wide_role<true, TW>(smem, a);
 }
 
 void core_attrs_once() {
@@ -1069,8 +1130,14 @@ void core_attrs_once() {
         (void)hipFuncSetAttribute((const void*)k1_core_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
         (void)hipFuncSetAttribute((const void*)k1_core_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
         (void)hipFuncSetAttribute((const void*)k1_core_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
-        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_fwd_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CORE_LDS);
+        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_wide_lds<1>());
+        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_wide_lds<2>());
+        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_wide_lds<3>());
+        (void)hipFuncSetAttribute((const void*)k1_core_bwd_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_wide_lds<4>());
         (void)hipFuncSetAttribute((const void*)k1_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     });
 }
@@ -1118,8 +1185,8 @@ K1Job ks_job(const void* A, int a_f32, long lda, const void* B, int b_f32, long 
 bool mha_fast_supported(int N, int d, int H, int prec) {
     if (prec != MOMA_PREC_BF16 || H <= 0 || d % H || N < 1) return false;
     const int hd = d / H;
-    // head dims up to 128: any N.  Wider heads (segments of 128 columns, k1_core_*_wide_kernel): one key tile per wave
-    return hd % 16 == 0 && (hd <= 128 || (hd <= 1024 && N <= KT * NW));
+    // head dims up to 128: any N.  Wider heads (segments of 128 columns, k1_core_*_wide_kernel): up to 4 key tiles per wave
+    return hd % 16 == 0 && (hd <= 128 || (hd <= 1024 && N <= KT * NW * 4));
 }
 
 hipError_t launch_mha_pack(const float* w_qkv, const float* w_proj, void* pack, int d, int with_t, hipStream_t st) {
@@ -1150,7 +1217,11 @@ hipError_t launch_mha_fwd_fast(const moma_mha_module_t* mods, int n_modules, int
     for (int i = 0; i < n_modules; ++i) ca.m[i] = CoreMod{(const bf16_raw*)mods[i].qkv16, (bf16_raw*)mods[i].attn16, mods[i].lse};
     const dim3 grid((N + 31) / 32, H, n_modules), block(NW * 64);
     const bool one = N <= KT * NW, full = hd == 128;                                                       // (:159-163)
-    if (hd > 128) hipLaunchKernelGGL(k1_core_fwd_wide_kernel, grid, block, CORE_LDS, st, ca);
+    const int tw = (N + KT * NW - 1) / (KT * NW);                  // key tiles per wave of the wide-head cores: 1 .. 4
+    if (hd > 128 && tw <= 1) hipLaunchKernelGGL(k1_core_fwd_wide_kernel<1>, grid, block, CORE_LDS, st, ca);
+    else if (hd > 128 && tw == 2) hipLaunchKernelGGL(k1_core_fwd_wide_kernel<2>, grid, block, CORE_LDS, st, ca);
+    else if (hd > 128 && tw == 3) hipLaunchKernelGGL(k1_core_fwd_wide_kernel<3>, grid, block, CORE_LDS, st, ca);
+    else if (hd > 128) hipLaunchKernelGGL(k1_core_fwd_wide_kernel<4>, grid, block, CORE_LDS, st, ca);
     else if (one && full) hipLaunchKernelGGL((k1_core_fwd_kernel<true, true>), grid, block, CORE_LDS, st, ca);
     else if (one) hipLaunchKernelGGL((k1_core_fwd_kernel<true, false>), grid, block, CORE_LDS, st, ca);
     else if (full) hipLaunchKernelGGL((k1_core_fwd_kernel<false, true>), grid, block, CORE_LDS, st, ca);
@@ -1197,7 +1268,11 @@ hipError_t launch_mha_bwd_fast(const void* pack, const void* x, int x_dtype, con
     if (e != hipSuccess) return e;
     // launch 2: the per-head core
     CoreBwdArgs ca{(const bf16_raw*)qkv16, dA16, lse, dpart, dqkv16, N, d, H};
-    if (d / H > 128) hipLaunchKernelGGL(k1_core_bwd_wide_kernel, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
+    const int tw = (N + KT * NW - 1) / (KT * NW);
+    if (d / H > 128 && tw <= 1) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<1>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<1>(), st, ca);
+    else if (d / H > 128 && tw == 2) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<2>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<2>(), st, ca);
+    else if (d / H > 128 && tw == 3) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<3>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<3>(), st, ca);
+    else if (d / H > 128) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<4>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<4>(), st, ca);
     else if (d / H == 128) hipLaunchKernelGGL(k1_core_bwd_kernel<true>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
     else hipLaunchKernelGGL(k1_core_bwd_kernel<false>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
     e = hipGetLastError();
