@@ -142,7 +142,10 @@ def _free_port():
     return port
 
 
-_SMALL = ["--steps", "6", "--warmup", "5", "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline"]
+# (learning rate 0.01: at the bench's 0.05 this 32-sample / 64-pixel miniature is chaotic -- the loss after five steps differs by
+#  +-0.6 from run to run -- and once in a while diverges to NaN, which bench.py rightly refuses to report)
+_SMALL = ["--steps", "6", "--warmup", "5", "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline",
+          "--learning_rate", "0.01"]
 
 
 def _check_two_rank_line(out, dp, steps=6, warmup=5):
