@@ -565,7 +565,8 @@ def main():
                                    f"kernels: MOMA_BN={os.environ.get('MOMA_BN', 'hip')} MOMA_DW={os.environ.get('MOMA_DW', 'hip')} "
                                    f"MOMA_SE={os.environ.get('MOMA_SE', 'hip')}), KD kernels {a.moma_prec}",
                        "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank",
-                       "step_graphs": {"enabled": bool(a.graph_student), "timed_steps_replayed": int(replayed)}},
+                       "step_graphs": {"enabled": bool(a.graph_student), "timed_steps_replayed": int(replayed),
+                                       "DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}},
             "roofline": roof,
         }
         if distributed:      # what the N>1 line was measured with (the driver checks it against its own launch)

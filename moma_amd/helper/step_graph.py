@@ -189,7 +189,11 @@ class StepGraphs:
 
     def _capture(self, key, images, labels):
         st = self.st
+        from .graphs import replay_is_safe
         from .loops_moma import _unwrap
+        if not replay_is_safe(images.device):               # (runtime hazard, ../hip_env.py: the loop stays eager)
+            self.enabled = False
+            return None
         dev = images.device
         trainer, contrast, kd = st.trainer, st.contrast, st.criterion_kd
         cap = _Captured()

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import moma_amd  # noqa: E402,F401  (sets the HIP runtime switches of moma_amd/hip_env.py before any test touches the GPU)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

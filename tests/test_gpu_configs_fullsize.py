@@ -127,3 +127,57 @@ def test_config4_vit_base_to_resnet50_full_size_single_gpu_form():
                                               "--batch_size", "64", "--amp", "fp16", "--no_cpu_baseline"])
     assert contrast.memory.shape == (65536, 512) and opt.s_dim == 2048 and opt.t_dim == 768 and rec["scale"] > 1.0
     _check_kd_term(a, opt, contrast, kd, rec, heads=4)
+
+
+def _losses(argv, steps_per_epoch):
+    """per-step (loss, loss_kd) of bench.py's loop over several epochs, printing EVERY step (eager kernels + a read-back between
+    the replays of the step graphs)"""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from moma_amd.train_student_moma import build_training
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.dataset.synthetic import SyntheticLoader
+
+    old = sys.argv
+    sys.argv = ["bench.py"] + argv
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    dev = torch.device("cuda", 0)
+    torch.backends.cudnn.benchmark = False
+    opt = bench.make_opt(a, 0, 1)
+    opt.trace, opt.print_freq = [], 1
+    torch.manual_seed(12345)
+    model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
+    trainer = ContrastTrainer(opt)
+    for ep, n in enumerate(steps_per_epoch):
+        loader = SyntheticLoader(n, a.batch_size, a.image_size, a.n_cls, 12345 + ep, dev)
+        train_distill_moma(ep, loader, module_list, criterion_list, trainer, contrast, optimizer, opt)
+    torch.cuda.synchronize()
+    sg = getattr(trainer, "_step_graphs", None)
+    finite = all(bool(torch.isfinite(p).all()) for p in model_s.parameters())
+    return (np.array([float(t[0]) for t in opt.trace]), np.array([float(t[2]) for t in opt.trace]),
+            0 if sg is None else sg.replays, finite)
+
+
+def test_config2_step_graphs_survive_eager_work_between_replays():
+    """Round 4: with the ROCm runtime's graph packet capture on, a captured memset node (ATen zeroes the semaphores of its column
+    reductions that way: the bias gradients of the ViT's wide Linear layers) stops working once eager kernels run between two
+    replays -- the ViT-S pair of configs[2] went to NaN two steps after the loop's first print.  moma_amd/hip_env.py switches
+    the packet capture off, helper/graphs.py:replay_is_safe() checks the live runtime before any capture.  Here: configs[2] at
+    full size, two epochs, a print (device arithmetic + read-back) after EVERY step; graphs against the eager loop."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd.helper.graphs import replay_is_safe
+    assert replay_is_safe(torch.device("cuda", 0))            # (this box's runtime with the package's environment)
+    argv = ["--model", "vit_small_patch16_224", "--head", "None", "--num_heads", "8", "--batch_size", "256", "--image_size", "224",
+            "--learning_rate", "0.005", "--no_cpu_baseline"]
+    lg, kg, replays, finite_g = _losses(argv, [5, 6])
+    le, ke, none, finite_e = _losses(argv + ["--no_graph_student"], [5, 6])
+    assert replays == 2 + 6 and none == 0                     # (the ViT has no BatchNorm: one variant, captured at the 4th step)
+    assert finite_g and finite_e and np.isfinite(lg).all() and np.isfinite(kg).all()
+    np.testing.assert_allclose(lg, le, rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(kg, ke, rtol=5e-3, atol=5e-3)

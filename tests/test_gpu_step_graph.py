@@ -228,3 +228,18 @@ def test_graphed_inference_capture_inside_a_live_autocast_context():
     assert len(g._graphs) == 1
     assert torch.isfinite(out2).all() and torch.allclose(out2, ref2, rtol=2e-2, atol=2e-2)
     assert not torch.allclose(out2, ref, rtol=1e-3, atol=1e-3)             # (it did follow the new weights)
+
+
+def test_runtime_replays_captured_memsets_after_eager_work():
+    """The hazard behind moma_amd/hip_env.py (ROCm 7.2 graph packet capture: a captured hipMemsetAsync node stops working once
+    eager kernels ran between replays -- garbage from every ATen column sum behind it).  The package's import must have switched the
+    packet capture off before the first HIP call, and the self-test every capture of this package consults must pass on this box."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import moma_amd  # noqa: F401
+    from moma_amd.helper import graphs
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    graphs._REPLAY_SAFE.clear()
+    assert graphs.replay_is_safe(torch.device("cuda", 0))
+    assert graphs._REPLAY_SAFE == {0: True}

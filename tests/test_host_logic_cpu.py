@@ -84,3 +84,19 @@ def test_graphed_inference_contract_on_cpu_is_eager():
         all_feats, _ = g(x, is_feat=True, full_feats=True)
     assert len(feats) == 1 and torch.equal(feats[0], ref_feats[-1]) and torch.equal(logits, ref_logits)
     assert len(all_feats) == len(ref_feats)
+
+
+def test_hip_env_switch_is_set_at_import_and_respects_the_caller():
+    """moma_amd/hip_env.py: importing the package sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (before the process's first HIP call); a
+    value the caller exported is left alone and configure() reports that the switch is not in place."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, moma_amd; from moma_amd import hip_env; print(os.environ[hip_env.SWITCH], hip_env.configure())"
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["0", "True"]
+    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "False"]
