@@ -23,6 +23,16 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
     return *reinterpret_cast<bf16_raw*>(&b);
 }
 
+// two floats -> one word of two bf16 (lo in bits 0..15), round to nearest even: ONE v_cvt_pk_bf16_f32.  Written as
+// `f32_to_bf16(lo) | f32_to_bf16(hi) << 16` hipcc pairs the conversions of a 16-byte store the wrong way round (values 0,2 / 1,3)
+// and puts the words together again with v_and / v_lshl / 2 x v_or_sdwa: 20 VALU instructions per store instead of 12 -- seen
+// in round 4 in the partial stores of the one-pass K2 kernel, whose last tile took 2.9 us instead of ~1
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 // value of lane l ^ 32 (the other half of the wave) by one v_permlane32_swap -- a VALU instruction; __shfl_xor(v, 32) is a
 // ds_bpermute, i.e. an LDS round trip with a wait
 __device__ __forceinline__ float other_half(float v) {

@@ -528,10 +528,10 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint4 v;
-                v.x = (unsigned)f32_to_bf16(O[c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[c][8 * g + 1]) << 16);
-                v.y = (unsigned)f32_to_bf16(O[c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[c][8 * g + 3]) << 16);
-                v.z = (unsigned)f32_to_bf16(O[c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[c][8 * g + 5]) << 16);
-                v.w = (unsigned)f32_to_bf16(O[c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g + 7]) << 16);
+                v.x = pack_bf16x2(O[c][8 * g + 0], O[c][8 * g + 1]);
+                v.y = pack_bf16x2(O[c][8 * g + 2], O[c][8 * g + 3]);
+                v.z = pack_bf16x2(O[c][8 * g + 4], O[c][8 * g + 5]);
+                v.w = pack_bf16x2(O[c][8 * g + 6], O[c][8 * g + 7]);
                 dst[(c * 2 + g) * 64] = v;     // (non-temporal stores: same kernel time, +3 us on the combine that reads them back)
             }
         }
@@ -1086,10 +1086,10 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
     float* xs = reinterpret_cast<float*>(smem + 4 * HCT * 2 * 64 * 16) + rb * 64;             // l [32], max [32] of kh = 1
     auto packed = [&](int c, int g2) __attribute__((always_inline)) -> uint4 {
         uint4 v;
-        v.x = (unsigned)f32_to_bf16(O[c][8 * g2 + 0]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 1]) << 16);
-        v.y = (unsigned)f32_to_bf16(O[c][8 * g2 + 2]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 3]) << 16);
-        v.z = (unsigned)f32_to_bf16(O[c][8 * g2 + 4]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 5]) << 16);
-        v.w = (unsigned)f32_to_bf16(O[c][8 * g2 + 6]) | ((unsigned)f32_to_bf16(O[c][8 * g2 + 7]) << 16);
+        v.x = pack_bf16x2(O[c][8 * g2 + 0], O[c][8 * g2 + 1]);
+        v.y = pack_bf16x2(O[c][8 * g2 + 2], O[c][8 * g2 + 3]);
+        v.z = pack_bf16x2(O[c][8 * g2 + 4], O[c][8 * g2 + 5]);
+        v.w = pack_bf16x2(O[c][8 * g2 + 6], O[c][8 * g2 + 7]);
         return v;
     };
     auto add_packed = [&](int c, int g2, const uint4& v) __attribute__((always_inline)) {
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float a = __builtin_amdgcn_exp2f(x[2 * i] - r_ref), b = __builtin_amdgcn_exp2f(x[2 * i + 1] - r_ref);
-                        pk[i] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+                        pk[i] = pack_bf16x2(a, b);
                     }
                     w0 = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                     w1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -1592,7 +1592,7 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float lo = __uint_as_float(wv[i] << 16) * f, hi = __uint_as_float(wv[i] & 0xffff0000u) * f;
-                wv[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                wv[i] = pack_bf16x2(lo, hi);
             }
         }
         pa[0] = __builtin_bit_cast(bf16x8, u32x4{wv[0], wv[1], wv[2], wv[3]});
@@ -1697,10 +1697,10 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         uint4 v;
-                        v.x = (unsigned)f32_to_bf16(O[s][c][8 * g + 0]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 1]) << 16);
-                        v.y = (unsigned)f32_to_bf16(O[s][c][8 * g + 2]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 3]) << 16);
-                        v.z = (unsigned)f32_to_bf16(O[s][c][8 * g + 4]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 5]) << 16);
-                        v.w = (unsigned)f32_to_bf16(O[s][c][8 * g + 6]) | ((unsigned)f32_to_bf16(O[s][c][8 * g + 7]) << 16);
+                        v.x = pack_bf16x2(O[s][c][8 * g + 0], O[s][c][8 * g + 1]);
+                        v.y = pack_bf16x2(O[s][c][8 * g + 2], O[s][c][8 * g + 3]);
+                        v.z = pack_bf16x2(O[s][c][8 * g + 4], O[s][c][8 * g + 5]);
+                        v.w = pack_bf16x2(O[s][c][8 * g + 6], O[s][c][8 * g + 7]);
                         dst[(cl * 2 + g) * 64] = v;
                     }
                 }
