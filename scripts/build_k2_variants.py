@@ -1,0 +1,49 @@
+"""Ablation builds of the one-pass K2 kernel (timing experiments only: the variants compute garbage).  Each variant is a text
+substitution on a copy of csrc/infonce_fused.hip, linked with the product's other objects into moma_amd/lib/variants/libmoma_<name>.so;
+select one with MOMA_HIP_LIB=<path>.   usage: python scripts/build_k2_variants.py [names...]"""
+import os, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "moma_amd", "csrc", "infonce_fused.hip")
+OBJ = os.path.join(ROOT, "moma_amd", "lib", "obj")
+OUT = os.path.join(ROOT, "moma_amd", "lib", "variants")
+LOOP_END = '''            if (t + NBUF - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");     // (one two-way branch, not the general switch)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // the next iteration's first A fragments'''
+VARIANTS = {
+    "base": [],
+    "nobar": [(LOOP_END, LOOP_END.replace("            __builtin_amdgcn_s_barrier();\n", ""))],
+    "nobar_novm": [(LOOP_END, "            // the next iteration's first A fragments")],
+    "noscorewait": [("            wait_lgkm(ahead + pre);\n", "")],
+    "nopvwait": [('                if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");\n'
+                  '                else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");\n'
+                  '                else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");\n'
+                  '                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n                __builtin_amdgcn_sched_barrier(0);\n                s16x4* k4', "                s16x4* k4")],
+    "norefill": [("                if ((ks & 3) == 1) dma_piece<D, REFILL == 2>(ks >> 2, dl, queue, rkey0, K, rbuf, wave, lane);\n", "")],
+    "nosoftmax": [('                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_a(c - SM_SHIFT);\n', ""),
+                  ('                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_b(c - SM_SHIFT);\n', "")],
+}
+VARIANTS["nowaits"] = VARIANTS["nobar_novm"] + VARIANTS["noscorewait"] + VARIANTS["nopvwait"]
+VARIANTS["nowaits_norefill"] = VARIANTS["nowaits"] + VARIANTS["norefill"]
+VARIANTS["noscorereads"] = [('        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");',
+                             '        asm volatile("; no read %0 %1" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]) : "memory");')]
+VARIANTS["nowaits_norefill_noscorereads"] = VARIANTS["nowaits_norefill"] + VARIANTS["noscorereads"]
+VARIANTS["nowaits_noscorereads"] = VARIANTS["nowaits"] + VARIANTS["noscorereads"]
+names = sys.argv[1:] or list(VARIANTS)
+os.makedirs(OUT, exist_ok=True)
+text = open(SRC).read()
+objs = [os.path.join(OBJ, f) for f in os.listdir(OBJ) if f.endswith(".o") and f != "infonce_fused.o"]
+for name in names:
+    t = text
+    for old, new in VARIANTS[name]:
+        assert t.count(old) == 1, (name, old[:60], t.count(old))
+        t = t.replace(old, new)
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "infonce_fused.hip")
+        open(src, "w").write(t)
+        obj = os.path.join(tmp, "v.o")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                        f"-I{os.path.dirname(SRC)}", "-c", src, "-o", obj], check=True)
+        lib = os.path.join(OUT, f"libmoma_{name}.so")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib, obj, *objs], check=True)
+    print("built", name, flush=True)
