@@ -147,12 +147,14 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
  * One pre-pack launch over the distinct q pointers, ONE launch of the one-pass kernel over every (term, query tile, key chunk) --
  * sized to one workgroup per compute unit over all terms, the queues streamed back to back --, one combine launch: 3 launches
  * for any number of terms (<= 4).  Per term the outputs of moma_infonce_fused; dq either for every term or for none (a query
- * shared by two terms gets two dq buffers: the caller adds them).  bf16 policy + bf16 queues + d in {128, 256, 384, 512} only:
- * moma_infonce_fused_multi_workspace_bytes() returns 0 otherwise and the caller makes one moma_infonce_fused call per term. */
+ * shared by two terms gets two dq buffers: the caller adds them).  The one-sweep kernel takes the bf16 policy with bf16 queues and
+ * d in {128, 256, 384, 512}; every other configuration moma_infonce_fused accepts (wide rows, exact fp32, fp32 queues) is served
+ * by the same entry point term by term on the stream, through ONE workspace of moma_infonce_fused's size -- at those shapes a
+ * term's own passes fill the chip and are not HBM-bound, so there is no sweep to share.  Queues are bf16 or fp32 per `qdtype`. */
 typedef struct moma_infonce_term {
     const float* q;        /* [B,d] fp32  */
     const float* k;        /* [B,d] fp32  */
-    const void* queue;     /* [K,d] bf16  */
+    const void* queue;     /* [K,d] bf16 / fp32 (qdtype) */
     float* loss_rows;      /* [B] out     */
     float* lse;            /* [B] out     */
     int32_t* top1;         /* [B] out     */

@@ -188,7 +188,11 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
 }
 
 size_t moma_infonce_fused_multi_workspace_bytes(int n_terms, int B, int d, int K, int qdtype, int prec) {
-    return infonce_multi_supported(n_terms, B, d, K, qdtype, prec) ? infonce_multi_workspace_bytes(n_terms, B, d, K) : 0;
+    if (n_terms < 1 || n_terms > 4 || B <= 0 || d <= 0 || K <= 0 || bad_dt(qdtype) || bad_prec(prec)) return 0;
+    if (infonce_multi_supported(n_terms, B, d, K, qdtype, prec)) return infonce_multi_workspace_bytes(n_terms, B, d, K);
+    // no one-sweep kernel for this configuration (wide rows, exact fp32, fp32 queue under the bf16 policy): the terms go through
+    // moma_infonce_fused's own path one after the other on the stream and share ONE workspace of that call's size
+    return moma_infonce_fused_workspace_bytes(B, d, K, qdtype, prec);
 }
 
 int moma_infonce_fused_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* workspace,
@@ -196,16 +200,26 @@ int moma_infonce_fused_multi(const moma_infonce_term_t* terms, int n_terms, int 
     if (!terms || !workspace) return MOMA_E_NULL;
     if (n_terms < 1 || n_terms > 4 || B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
-    if (!infonce_multi_supported(n_terms, B, d, K, qdtype, prec)) return MOMA_E_UNSUPPORTED;
     for (int i = 0; i < n_terms; ++i) {
         const moma_infonce_term_t& t = terms[i];
         if (!t.q || !t.k || !t.queue || !t.loss_rows || !t.lse || !t.top1) return MOMA_E_NULL;
         if ((t.dq != nullptr) != (terms[0].dq != nullptr)) return MOMA_E_UNSUPPORTED;     // every term with dq, or none
         if (misaligned(t.q, 16) || misaligned(t.k, 4) || misaligned(t.queue, 16)) return MOMA_E_ALIGN;
     }
-    if (workspace_bytes < infonce_multi_workspace_bytes(n_terms, B, d, K)) return MOMA_E_WORKSPACE;
+    if (workspace_bytes < moma_infonce_fused_multi_workspace_bytes(n_terms, B, d, K, qdtype, prec)) return MOMA_E_WORKSPACE;
     if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
-    return hip_rc(launch_infonce_multi(terms, n_terms, B, d, K, inv_T, workspace, (hipStream_t)stream));
+    if (infonce_multi_supported(n_terms, B, d, K, qdtype, prec))
+        return hip_rc(launch_infonce_multi(terms, n_terms, B, d, K, inv_T, workspace, (hipStream_t)stream));
+    // term by term (stream order makes the shared workspace safe).  At these shapes every term's passes already fill the chip and
+    // are bound by the matrix pipe / L2 delivery, not by HBM (d = 1280 bf16: 1.2 TB/s; exact fp32: 0.35 TB/s): merging the terms'
+    // launches would not read the queues any less
+    for (int i = 0; i < n_terms; ++i) {
+        const moma_infonce_term_t& t = terms[i];
+        const int rc = moma_infonce_fused_q(t.q, nullptr, t.k, t.queue, B, d, K, inv_T, t.loss_rows, t.lse, t.top1, t.dq, workspace,
+                                            workspace_bytes, qdtype, prec, stream, nullptr, nullptr, nullptr);
+        if (rc != MOMA_OK) return rc;
+    }
+    return MOMA_OK;
 }
 
 int moma_mha_saved_state(int N, int d, int H, int prec) {

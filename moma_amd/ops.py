@@ -394,7 +394,8 @@ class _InfoNCEFusedMulti(torch.autograd.Function):
         K = queues[0].shape[0]
         dev = qs[0].device
         need_grad = any(ctx.needs_input_grad[2 + 3 * i] for i in range(n))
-        ws = torch.empty(lib.moma_infonce_fused_multi_workspace_bytes(n, B, d, K, DT_BF16, prec), device=dev, dtype=torch.uint8)
+        qd = _qdtype(queues[0])
+        ws = torch.empty(max(lib.moma_infonce_fused_multi_workspace_bytes(n, B, d, K, qd, prec), 16), device=dev, dtype=torch.uint8)
         terms = (_lib.InfoNCETerm * n)()
         outs, dqs = [], []
         for i in range(n):
@@ -409,7 +410,7 @@ class _InfoNCEFusedMulti(torch.autograd.Function):
             outs += [loss_rows, lse, top1]
             dqs.append(dq)
         with _timed("moma_infonce_fused_multi"):
-            check(lib.moma_infonce_fused_multi(C.cast(terms, C.c_void_p), n, B, d, K, float(1.0 / T), _ptr(ws), ws.numel(), DT_BF16,
+            check(lib.moma_infonce_fused_multi(C.cast(terms, C.c_void_p), n, B, d, K, float(1.0 / T), _ptr(ws), ws.numel(), qd,
                                                prec, _stream()), "moma_infonce_fused_multi")
         if need_grad:
             ctx.save_for_backward(*dqs)
@@ -428,14 +429,13 @@ class _InfoNCEFusedMulti(torch.autograd.Function):
 
 
 def infonce_fused_multi(terms, T: float, prec="fp32"):
-    """terms = [(q, k, queue), ...] over queues of one shape -> [(loss_rows, lse, top1), ...], computed in ONE sweep
-    (moma_infonce_fused_multi) where the one-pass kernel takes the configuration, else one moma_infonce_fused call per term."""
-    lib = _lib.load()
+    """terms = [(q, k, queue), ...] over queues of one shape and dtype -> [(loss_rows, lse, top1), ...] through ONE library call
+    (moma_infonce_fused_multi): one sweep where the one-pass bf16 kernel takes the configuration, term by term inside the
+    library otherwise (wide rows, exact fp32).  Terms of different shapes: one moma_infonce_fused call each."""
     pc = prec_code(prec)
     q0, _, queue0 = terms[0]
-    same = all(q.shape == q0.shape and queue.shape == queue0.shape and queue.dtype == torch.bfloat16 for q, _, queue in terms)
-    if len(terms) > 1 and same and q0.is_cuda and \
-            lib.moma_infonce_fused_multi_workspace_bytes(len(terms), q0.shape[0], q0.shape[1], queue0.shape[0], DT_BF16, pc) > 0:
+    same = all(q.shape == q0.shape and queue.shape == queue0.shape and queue.dtype == queue0.dtype for q, _, queue in terms)
+    if len(terms) > 1 and len(terms) <= 4 and same and q0.is_cuda:
         flat = _InfoNCEFusedMulti.apply(float(T), pc, *[t for term in terms for t in term])
         return [tuple(flat[3 * i:3 * i + 3]) for i in range(len(terms))]
     return [infonce_fused(q, k, queue, T, prec) for q, k, queue in terms]
