@@ -60,6 +60,7 @@ def parse():
     p.add_argument("--channels_last", action="store_true",
                    help="NHWC backbones (MIOpen's depthwise backward is ~7x slower in NHWC on gfx950: off by default)")
     p.add_argument("--learning_rate", type=float, default=0.05)
+    p.add_argument("--print_freq", type=int, default=10 ** 9, help="loop print (device arithmetic + read-back) every N steps; default: only at step 0")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_batch", type=int, default=16)
     p.add_argument("--cpu_steps", type=int, default=15)    # ~10 s of host work at B=16
@@ -203,7 +204,7 @@ def make_opt(a, rank, world):
     return argparse.Namespace(
         distill="moma", head=a.head, feat_dim=a.feat_dim, attn="self", mem="MoCo", nce_k=a.nce_k, nce_t=0.15,
         alpha=0.999, cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=int(os.environ.get("LOCAL_RANK", 0)),
-        multiprocessing_distributed=world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1", print_freq=10 ** 9, batch_size=a.batch_size, rank=rank,
+        multiprocessing_distributed=world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1", print_freq=a.print_freq, batch_size=a.batch_size, rank=rank,
         world_size=world, model_s=a.model, model_t=a.model_t or a.model, std_pre=None, tec_pre=None, path_t=None,
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=a.learning_rate, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,

@@ -29,6 +29,15 @@ VARIANTS["noscorereads"] = [('        asm volatile("ds_read_b128 %0, %1 offset:%
                              '        asm volatile("; no read %0 %1" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]) : "memory");')]
 VARIANTS["nowaits_norefill_noscorereads"] = VARIANTS["nowaits_norefill"] + VARIANTS["noscorereads"]
 VARIANTS["nowaits_noscorereads"] = VARIANTS["nowaits"] + VARIANTS["noscorereads"]
+# score accumulator in AGPRs (is the LDS return path contending with the MFMA's VGPR result writes?)
+VARIANTS["scoreacc_agpr"] = [
+    ('asm volatile("s_nop 1\\n\\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "v"(c0));',
+     'asm volatile("s_nop 1\\n\\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&a"(x) : "v"(kf[ks % RD]), "v"(qf[ks]), "a"(c0));'),
+    ('asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\\n\\ts_nop 15\\n\\ts_nop 3" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));',
+     'asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\\n\\ts_nop 15\\n\\ts_nop 3" : "+a"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));'),
+    ('                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));',
+     '                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));'),
+]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()
