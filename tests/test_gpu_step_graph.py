@@ -243,3 +243,23 @@ def test_runtime_replays_captured_memsets_after_eager_work():
     graphs._REPLAY_SAFE.clear()
     assert graphs.replay_is_safe(torch.device("cuda", 0))
     assert graphs._REPLAY_SAFE == {0: True}
+
+
+def test_a_runtime_that_fails_the_replay_self_test_keeps_the_eager_loop():
+    """helper/graphs.py:replay_is_safe() False (a process whose HIP runtime was initialised with graph packet capture on) -> no
+    capture anywhere: the step graphs and the teacher's GraphedInference both stay eager, the loop runs and equals the eager run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd.helper import graphs
+    saved = dict(graphs._REPLAY_SAFE)
+    try:
+        graphs._REPLAY_SAFE.clear()
+        graphs._REPLAY_SAFE[0] = False
+        a = _run(True, "resnet8", True, "bf16", "bf16", None)
+    finally:
+        graphs._REPLAY_SAFE.clear()
+        graphs._REPLAY_SAFE.update(saved)
+    b = _run(False, "resnet8", True, "bf16", "bf16", None)
+    assert a["replays"] == 0 and b["replays"] == 0
+    assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"]
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=2e-4, atol=2e-4)
