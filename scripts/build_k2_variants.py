@@ -38,6 +38,15 @@ VARIANTS["scoreacc_agpr"] = [
     ('                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));',
      '                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));'),
 ]
+# combine experiments: two column tiles per block (half the blocks, the row statistics repeated half as often) / no q.k dot in the combine
+COMB_OLD = ('    hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,\n'
+            '                          k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);')
+VARIANTS["comb_tpb2"] = [(COMB_OLD, COMB_OLD.replace("dq ? d / 32 : 1", "dq ? d / 64 : 1").replace("0L, 1, 1, m_part", "0L, 1, 2, m_part"))]
+VARIANTS["comb_tpb4"] = [(COMB_OLD, COMB_OLD.replace("dq ? d / 32 : 1", "dq ? d / 128 : 1").replace("0L, 1, 1, m_part", "0L, 1, 4, m_part"))]
+NOS0 = [('        for (int c = l32 * 4; c < D; c += 128) {\n            const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);',
+         '        for (int c = l32 * 4; c < D && inv_T < 0.f; c += 128) {\n            const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);')]
+VARIANTS["comb_nos0"] = NOS0
+VARIANTS["comb_tpb2_nos0"] = VARIANTS["comb_tpb2"] + NOS0
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()

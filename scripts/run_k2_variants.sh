@@ -13,5 +13,10 @@ if not f: print(sys.argv[2],"no stats"); raise SystemExit
 for r in csv.DictReader(open(f[0])):
     if "flash_kernel" in r["Name"] and "true" in r["Name"] or "small_kernel" in r["Name"]:
         print("%-14s %s avg %.2f us  min %.2f"%(sys.argv[2], r["Name"].split("(")[0][-28:], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
+t=glob.glob(sys.argv[1]+"/*/*kernel_trace.csv")
+if t:
+    d=sorted((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(t[0])) if "combine_kernel" in r["Kernel_Name"])
+    up=d[len(d)//2:]
+    if up: print("%-14s combine (dq launches) avg %.2f us  min %.2f  max %.2f"%(sys.argv[2], sum(up)/len(up), up[0], up[-1]))
 PY
 done
