@@ -47,6 +47,8 @@ NOS0 = [('        for (int c = l32 * 4; c < D; c += 128) {\n            const fl
          '        for (int c = l32 * 4; c < D && inv_T < 0.f; c += 128) {\n            const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);')]
 VARIANTS["comb_nos0"] = NOS0
 VARIANTS["comb_tpb2_nos0"] = VARIANTS["comb_tpb2"] + NOS0
+for _sd in (2, 4, 5, 6):
+    VARIANTS[f"wpv_sd{_sd}"] = [("#define MOMA_K2_WPV_SD 3 ", f"#define MOMA_K2_WPV_SD {_sd} ")]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()

@@ -11,7 +11,7 @@ import csv,glob,sys
 f=glob.glob(sys.argv[1]+"/*/*kernel_stats.csv")
 if not f: print(sys.argv[2],"no stats"); raise SystemExit
 for r in csv.DictReader(open(f[0])):
-    if "flash_kernel" in r["Name"] and "true" in r["Name"] or "small_kernel" in r["Name"]:
+    if "flash_kernel" in r["Name"] and "true" in r["Name"] or "small_kernel" in r["Name"] or "wide_" in r["Name"]:
         print("%-14s %s avg %.2f us  min %.2f"%(sys.argv[2], r["Name"].split("(")[0][-28:], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
 t=glob.glob(sys.argv[1]+"/*/*kernel_trace.csv")
 if t:
