@@ -67,6 +67,8 @@ def parse():
     p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
     p.add_argument("--no_graph_student", dest="graph_student", action="store_false",
                    help="issue the step launch by launch instead of replaying it from HIP graphs (helper/step_graph.py)")
+    p.add_argument("--no_prefetch_queue", dest="prefetch_queue", action="store_false",
+                   help="skip the side-stream sweep that warms the Infinity Cache with the queue ahead of K2 (experiment switch)")
     p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
                    help="queue the teacher / key side of the step on the main stream instead of a second HIP stream")
     return p.parse_args()
@@ -209,7 +211,7 @@ def make_opt(a, rank, world):
         std_strict=True, tec_strict=True, n_cls=a.n_cls, dataset="synthetic", image_size=a.image_size,
         learning_rate=a.learning_rate, momentum=0.9, weight_decay=1e-4, moma_prec=a.moma_prec, queue_dtype=a.queue_dtype,
         amp=None if a.amp == "none" else a.amp, channels_last=a.channels_last, moma_fused=True,
-        shuffle_bn="per_rank", num_heads=a.num_heads, graph_student=a.graph_student,
+        shuffle_bn="per_rank", num_heads=a.num_heads, graph_student=a.graph_student, prefetch_queue=a.prefetch_queue,
         # (two processes time-slicing ONE GPU -- the CPU-side rehearsal mode -- collapse when each drives two streams)
         overlap_teacher=a.overlap_teacher and (os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1" or
                                                os.environ.get("MOMA_BENCH_FORCE_OVERLAP") == "1"))
