@@ -128,8 +128,9 @@ class GraphedInference:
         270-272) -- before a timed region; returns True when the variant is (now) graphed.
         Call it ON THE STREAM THE REPLAYS WILL RUN ON (the loop's side stream under overlap_teacher): library workspaces
         (hipBLASLt / MIOpen) belong to the capturing stream, and a replay that runs beside other work of that stream races on
-        them (seen: a variant captured on the main stream and replayed on the side stream next to the student forward
-        returned garbage logits)."""
+        them (seen in round 3: a variant captured on the main stream and replayed on the side stream next to the student forward
+        returned garbage logits -- possibly also an instance of the runtime hazard of ../hip_env.py, found a round later; the
+        per-stream rule stays either way)."""
         if not (self.enabled and x.is_cuda):
             return False
         if any(m.training for m in self._mods if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
