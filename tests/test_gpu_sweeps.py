@@ -1,5 +1,6 @@
-"""Randomised parity sweeps on the GPU (scripts/sweep_k2.py, scripts/sweep_k1.py): the bf16-policy K2 call and the K1 module
-against fp64 restatements over ragged shapes and every kernel width.  Each sweep runs in a child process (a few seconds)."""
+"""Randomised parity sweeps on the GPU (scripts/sweep_k2.py, scripts/sweep_k1.py, scripts/sweep_k2_f32.py): the bf16-policy K2 call,
+the K1 module, the exact-fp32 one-pass K2 and the multi-term entry against fp64 restatements over ragged shapes (K = 1 included),
+large logits and every kernel width.  Each sweep runs in a child process (a few seconds)."""
 import os
 import subprocess
 import sys
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,cases,seed", [("sweep_k2.py", 120, 11), ("sweep_k1.py", 80, 5)])
+@pytest.mark.parametrize("script,cases,seed", [("sweep_k2.py", 120, 11), ("sweep_k1.py", 80, 5), ("sweep_k2_f32.py", 150, 2024)])
 def test_randomised_sweep(script, cases, seed):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
