@@ -64,3 +64,47 @@ def test_macro_f1_matches_reference_formula():
     f1 = 2 * (3 / 4) * (3 / 5) / ((3 / 4) + (3 / 5))
     assert abs(macro_f1(cm) - (f0 + f1) / 3) < 1e-12          # a class without true positives counts 0
     assert macro_f1(np.eye(4) * 7) == 1.0
+
+
+def test_every_entry_point_rejects_null_pointers_and_negative_sizes(lib_path):
+    """Contract of include/moma_hip.h: a negative return is an argument error, found BEFORE anything is enqueued.  Table-driven over
+    every int-returning entry point of the binding: (a) all pointers NULL, (b) dummy non-NULL pointers with every integer -1,
+    (c) the same with every integer 0 -- (a) and (b) must come back negative, (c) negative or 0 for an empty job; a positive value is a
+    hipError, i.e. a launch was attempted on this GPU-less box: the check was missing; the *_bytes functions answer 0 for such shapes."""
+    import ctypes as C
+    from moma_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(1 << 16)                      # zeroed host memory standing in for "some pointer"
+    ptr = C.cast(buf, C.c_void_p)
+    skip = {"moma_version", "moma_error_string", "moma_mha_saved_state"}
+    checked = 0
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        if name in skip:
+            continue
+        fn = getattr(lib, name)
+
+        def args(pointer, integer):
+            out = []
+            for t in argtypes:
+                if t is C.c_void_p:
+                    out.append(pointer)
+                elif t is C.c_float:
+                    out.append(C.c_float(0.5))
+                elif t is C.c_size_t:
+                    out.append(C.c_size_t(64))
+                else:
+                    out.append(t(integer))
+            return out
+        if restype is C.c_size_t:
+            if any(t in (C.c_int, C.c_int64) for t in argtypes):
+                assert fn(*args(ptr, -1)) == 0, name
+            continue
+        has_ptr = any(t is C.c_void_p for t in argtypes)
+        has_int = any(t in (C.c_int, C.c_int64) for t in argtypes)
+        if has_ptr:
+            assert fn(*args(None, 4)) < 0, (name, "NULL pointers")
+        if has_int:
+            assert fn(*args(ptr, -1)) < 0, (name, "negative sizes")
+            assert fn(*args(ptr, 0)) <= 0, (name, "zero sizes")       # (an empty job -- e.g. an EMA table without tensors -- may be a no-op)
+        checked += 1
+    assert checked >= 20
