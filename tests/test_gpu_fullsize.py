@@ -96,3 +96,45 @@ def test_ema_fixed_point_and_copy(env):
     ops.ema_update_(tab2, 0.0)                                          # m = 0 is the reference's "copy" use
     for a, b in zip(p, e2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Bq,d,Kq", [(130, 512, 4_300_000),      # one-pass kernel, 2.2e9 queue elements
+                                     (40, 512, 4_300_000),       # small-batch kernel
+                                     (40, 1280, 1_700_000),      # wide rows: two passes + the P scratch
+                                     (4, 2048, 1_100_000)])      # two register passes of Q
+def test_queue_beyond_2_31_elements(Bq, d, Kq):
+    """Maximum sizes: a queue of more than 2^31 elements (row offsets past 32 bits everywhere: LDS-DMA source addresses, the
+    P scratch of the wide path, the enqueue's slot address).  K2's loss / dq against fp64 torch on the same bf16 queue values, then
+    K3 at the wrap of that queue: the rows land in [K - 3, K) and [0, 4), bit for bit, nothing else changes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd import ops
+    assert Kq * d > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(Kq % 1000 + d)
+    q = torch.nn.functional.normalize(torch.randn(Bq, d, device="cuda", generator=g)).requires_grad_(True)
+    k = torch.nn.functional.normalize(q.detach() + 0.3 * torch.randn(Bq, d, device="cuda", generator=g))
+    queue = torch.empty(Kq, d, device="cuda", dtype=torch.bfloat16)
+    step = 1 << 18
+    for i in range(0, Kq, step):                                # (normalised in pieces: no fp32 copy of the whole queue)
+        n = min(step, Kq - i)
+        queue[i:i + n] = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g)).to(torch.bfloat16)
+    loss_rows, lse, top1 = ops.infonce_fused(q, k, queue, T, "bf16")
+    loss_rows.sum().backward()
+    q64 = q.detach().double().requires_grad_(True)
+    neg = torch.cat([q64 @ queue[i:i + step].double().T for i in range(0, Kq, step)], 1)
+    logits = torch.cat([(q64 * k.double()).sum(1, keepdim=True), neg], 1) / T
+    ref = torch.nn.functional.cross_entropy(logits, torch.zeros(Bq, dtype=torch.long, device="cuda"), reduction="none")
+    ref.sum().backward()
+    assert float(((loss_rows.detach().double() - ref.detach()).abs() / ref.detach().abs().clamp_min(1.0)).max()) < 1e-3
+    assert float((q.grad.double() - q64.grad).abs().max() / q64.grad.abs().max()) < 2e-2
+    del logits, neg
+    # K3 across the end of the ring
+    rows = torch.randn(7, d, device="cuda", generator=g)
+    probe = torch.cat([torch.arange(0, 6, device="cuda"), torch.arange(Kq - 6, Kq, device="cuda"), torch.tensor([Kq // 2], device="cuda")])
+    before = queue[probe].clone()
+    ops.enqueue_(queue, rows, Kq - 3)
+    want = before.clone()
+    r16 = rows.to(torch.bfloat16)
+    want[9:12] = r16[0:3]                                        # slots K-3, K-2, K-1 (probe positions 9..11)
+    want[0:4] = r16[3:7]                                         # slots 0..3
+    assert torch.equal(queue[probe], want)
