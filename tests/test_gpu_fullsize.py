@@ -98,11 +98,13 @@ def test_ema_fixed_point_and_copy(env):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("Bq,d,Kq", [(130, 512, 4_300_000),      # one-pass kernel, 2.2e9 queue elements
-                                     (40, 512, 4_300_000),       # small-batch kernel
-                                     (40, 1280, 1_700_000),      # wide rows: two passes + the P scratch
-                                     (4, 2048, 1_100_000)])      # two register passes of Q
-def test_queue_beyond_2_31_elements(Bq, d, Kq):
+@pytest.mark.parametrize("Bq,d,Kq,prec", [(130, 512, 4_300_000, "bf16"),      # one-pass kernel, 2.2e9 queue elements
+                                          (40, 512, 4_300_000, "bf16"),       # small-batch kernel
+                                          (40, 1280, 1_700_000, "bf16"),      # wide rows: two passes + the P scratch
+                                          (4, 2048, 1_100_000, "bf16"),       # two register passes of Q
+                                          (130, 512, 4_300_000, "fp32"),      # exact-fp32 one pass over an fp32 queue (8.8 GB)
+                                          (20, 1280, 1_700_000, "fp32")])     # ... segment-streamed
+def test_queue_beyond_2_31_elements(Bq, d, Kq, prec):
     """Maximum sizes: a queue of more than 2^31 elements (row offsets past 32 bits everywhere: LDS-DMA source addresses, the
     P scratch of the wide path, the enqueue's slot address).  K2's loss / dq against fp64 torch on the same bf16 queue values, then
     K3 at the wrap of that queue: the rows land in [K - 3, K) and [0, 4), bit for bit, nothing else changes."""
@@ -113,20 +115,22 @@ def test_queue_beyond_2_31_elements(Bq, d, Kq):
     g = torch.Generator(device="cuda").manual_seed(Kq % 1000 + d)
     q = torch.nn.functional.normalize(torch.randn(Bq, d, device="cuda", generator=g)).requires_grad_(True)
     k = torch.nn.functional.normalize(q.detach() + 0.3 * torch.randn(Bq, d, device="cuda", generator=g))
-    queue = torch.empty(Kq, d, device="cuda", dtype=torch.bfloat16)
+    qdt = torch.bfloat16 if prec == "bf16" else torch.float32
+    queue = torch.empty(Kq, d, device="cuda", dtype=qdt)
     step = 1 << 18
-    for i in range(0, Kq, step):                                # (normalised in pieces: no fp32 copy of the whole queue)
+    for i in range(0, Kq, step):                                # (normalised in pieces: no second copy of the whole queue)
         n = min(step, Kq - i)
-        queue[i:i + n] = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g)).to(torch.bfloat16)
-    loss_rows, lse, top1 = ops.infonce_fused(q, k, queue, T, "bf16")
+        queue[i:i + n] = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g)).to(qdt)
+    loss_rows, lse, top1 = ops.infonce_fused(q, k, queue, T, prec)
     loss_rows.sum().backward()
     q64 = q.detach().double().requires_grad_(True)
     neg = torch.cat([q64 @ queue[i:i + step].double().T for i in range(0, Kq, step)], 1)
     logits = torch.cat([(q64 * k.double()).sum(1, keepdim=True), neg], 1) / T
     ref = torch.nn.functional.cross_entropy(logits, torch.zeros(Bq, dtype=torch.long, device="cuda"), reduction="none")
     ref.sum().backward()
-    assert float(((loss_rows.detach().double() - ref.detach()).abs() / ref.detach().abs().clamp_min(1.0)).max()) < 1e-3
-    assert float((q.grad.double() - q64.grad).abs().max() / q64.grad.abs().max()) < 2e-2
+    tol_l, tol_g = (1e-3, 2e-2) if prec == "bf16" else (2e-5, 1e-4)
+    assert float(((loss_rows.detach().double() - ref.detach()).abs() / ref.detach().abs().clamp_min(1.0)).max()) < tol_l
+    assert float((q.grad.double() - q64.grad).abs().max() / q64.grad.abs().max()) < tol_g
     del logits, neg
     # K3 across the end of the ring
     rows = torch.randn(7, d, device="cuda", generator=g)
@@ -134,7 +138,7 @@ def test_queue_beyond_2_31_elements(Bq, d, Kq):
     before = queue[probe].clone()
     ops.enqueue_(queue, rows, Kq - 3)
     want = before.clone()
-    r16 = rows.to(torch.bfloat16)
+    r16 = rows.to(qdt)
     want[9:12] = r16[0:3]                                        # slots K-3, K-2, K-1 (probe positions 9..11)
     want[0:4] = r16[3:7]                                         # slots 0..3
     assert torch.equal(queue[probe], want)
