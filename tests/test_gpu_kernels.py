@@ -678,6 +678,49 @@ def test_mha_flash_long_sequence_fwd_bwd(ops, N, d, H):
         assert rel(a.grad, r.grad) < 5e-2, (nm, rel(a.grad, r.grad))
 
 
+def test_mha_at_the_full_queue_length(ops):
+    """Maximum size of the batch-token attention: attn = 'all' at the bench's queue, N = 2 B + K = 66048 tokens (reference
+    MoMA/mem_moco.py:139-147; its own op chain would materialise 4 x 66048^2 probabilities).  Forward against a blocked fp64
+    restatement on the GPU (2048 query rows at a time); backward through directional derivatives of L = sum(y * dy): <dL/dx, v>,
+    <dL/dWqkv, V> and <dL/dWproj, U> against central differences of the fp64 forward."""
+    N, d, H = 2 * 256 + 65536, 512, 4
+    hd = d // H
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.nn.functional.normalize(torch.randn(N, d, device="cuda", generator=g))
+    bound = 1.0 / np.sqrt(d)
+    w_qkv = (torch.rand(3 * d, d, device="cuda", generator=g) * 2 - 1) * bound * 6        # peaked rows: the softmax matters
+    b_qkv = (torch.rand(3 * d, device="cuda", generator=g) * 2 - 1) * bound
+    w_proj = (torch.rand(d, d, device="cuda", generator=g) * 2 - 1) * bound
+    b_proj = (torch.rand(d, device="cuda", generator=g) * 2 - 1) * bound
+    dy = torch.randn(N, d, device="cuda", generator=g) / N ** 0.5
+
+    def ref_forward(x_, wq_, wp_):
+        qkv = (x_ @ wq_.T + b_qkv.double()).reshape(N, 3, H, hd)
+        q, k, v = (qkv[:, i].permute(1, 0, 2).contiguous() for i in range(3))               # [H, N, hd]
+        out = torch.empty(N, d, device="cuda", dtype=torch.float64)
+        for r0 in range(0, N, 2048):
+            r1 = min(r0 + 2048, N)
+            p = torch.softmax(q[:, r0:r1] @ k.transpose(1, 2) * hd ** -0.5, dim=-1)          # [H, rows, N]
+            out[r0:r1] = (p @ v).permute(1, 0, 2).reshape(r1 - r0, d)
+        return out @ wp_.T + b_proj.double()
+    X, WQ, WP = x.double(), w_qkv.double(), w_proj.double()
+    y_ref = ref_forward(X, WQ, WP)
+    tin = [t.clone().requires_grad_(True) for t in (x, w_qkv, b_qkv, w_proj, b_proj)]
+    y = ops.mha(*tin, H, "bf16")
+    assert float((y.detach().double() - y_ref).abs().max() / y_ref.abs().max()) < 3e-2
+    (y * dy).sum().backward()
+    assert all(torch.isfinite(t.grad).all() for t in tin)
+    L = lambda x_, wq_, wp_: float((ref_forward(x_, wq_, wp_) * dy.double()).sum())
+    v = torch.randn(N, d, device="cuda", generator=g).double()
+    V = torch.randn(3 * d, d, device="cuda", generator=g).double() * bound
+    U = torch.randn(d, d, device="cuda", generator=g).double() * bound
+    eps = 1e-4
+    for name, got, fd in (("dx", float((tin[0].grad.double() * v).sum()), (L(X + eps * v, WQ, WP) - L(X - eps * v, WQ, WP)) / (2 * eps)),
+                          ("d_wqkv", float((tin[1].grad.double() * V).sum()), (L(X, WQ + eps * V, WP) - L(X, WQ - eps * V, WP)) / (2 * eps)),
+                          ("d_wproj", float((tin[3].grad.double() * U).sum()), (L(X, WQ, WP + eps * U) - L(X, WQ, WP - eps * U)) / (2 * eps))):
+        assert abs(got - fd) < 5e-2 * max(abs(fd), 1e-3), (name, got, fd)
+
+
 def test_mocoatt_attn_all_over_large_queue(ops):
     """MoCoAtt.forward(attn='all') (reference MoMA/mem_moco.py:124-126) with K = 8192: one attention over the
     N = 2B + K = 8224 tokens [q ; k ; queue], logits over the attended queue, gradient back to the student query -- G7's case
