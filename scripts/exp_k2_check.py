@@ -21,5 +21,5 @@ ref = torch.nn.functional.cross_entropy(logits, torch.zeros(B, dtype=torch.long,
 (ref.sum() if loss.dim() else ref.mean()).backward()
 lv = loss if loss.dim() else loss
 rv = ref if loss.dim() else ref.mean()
-print("loss max rel err", float(((lv.double() - rv).abs() / rv.abs().clamp_min(1.0)).max()),
+print("loss max rel err", float(((lv.detach().double() - rv.detach()).abs() / rv.detach().abs().clamp_min(1.0)).max()),
       " dq max err / max", float((dq.double() - q2.grad).abs().max() / q2.grad.abs().max()))
