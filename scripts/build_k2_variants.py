@@ -47,6 +47,12 @@ NOS0 = [('        for (int c = l32 * 4; c < D; c += 128) {\n            const fl
          '        for (int c = l32 * 4; c < D && inv_T < 0.f; c += 128) {\n            const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);')]
 VARIANTS["comb_nos0"] = NOS0
 VARIANTS["comb_tpb2_nos0"] = VARIANTS["comb_tpb2"] + NOS0
+# two interleaved accumulation chains in the score product (timing only: the odd k-steps accumulate into the registers of the
+# row-constant tuple) -- is the single dependent chain on a VGPR accumulator what the score product pays for?
+VARIANTS["score_two_chains"] = [
+    ('                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));\n            if (ks + RD < KS) rd(ks + RD);',
+     '                { if (ks & 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(kf[ks % RD]), "v"(qf[ks]));\n'
+     '                  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x) : "v"(kf[ks % RD]), "v"(qf[ks])); }\n            if (ks + RD < KS) rd(ks + RD);')]
 for _sd in (2, 4, 5, 6):
     VARIANTS[f"wpv_sd{_sd}"] = [("#define MOMA_K2_WPV_SD 3 ", f"#define MOMA_K2_WPV_SD {_sd} ")]
 names = sys.argv[1:] or list(VARIANTS)
