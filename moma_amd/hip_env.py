@@ -18,6 +18,10 @@ SWITCH = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
 def configure() -> bool:
-    """-> True when the switch is (now) set to 0 in this process's environment.  A caller's own setting is left alone."""
+    """-> True when the switch is (now) set to 0 in this process's environment.  A caller's own setting is left alone.
+    Also defaults HSA_ENABLE_IPC_MODE_LEGACY to 0: the host driver of this platform supports dmabuf IPC only, and without it RCCL's
+    intra-node transport (and any sharing of device tensors across processes) fails with `hipIpcGetMemHandle: invalid argument` --
+    every rank the CLI spawns (train_student_moma.py --multiprocessing-distributed, bench.py --gpus N) inherits it from here."""
     os.environ.setdefault(SWITCH, "0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return os.environ[SWITCH] == "0"
