@@ -62,6 +62,13 @@ class MomaStep:
         self.attn_in_shuffle = (opt.distill == "moma" and getattr(opt, "attn", "self") in ("self_mix", "self_nomix")
                                 and not self.mocoatt)
         self.ema_ok = None
+        if opt.distill == "moma" and contrast is not None and hasattr(contrast, "memory_s"):
+            # --mem MoCoST / MoCoSSTT: the reference loop calls contrast(q=f_s, k=k, all_k=all_k) for every memory
+            # (helper/loops_moma.py:331) and never produces the second key set k_t these two need -- there it dies inside the first
+            # step (MoCoST.forward: missing argument k_t; MoCoSSTT.forward: None.detach()).  Same verdict here, said up front:
+            raise NotImplementedError(f"--mem {type(contrast).__name__}: the distillation loop supplies (q, k, all_k) only -- the "
+                                      "reference's own loop fails on this memory in its first step (no k_t is ever computed); "
+                                      "the dual-queue memories are usable as modules (forward / forward_fused), not from this loop")
         self.overlap = (getattr(opt, "overlap_teacher", False) and opt.distill == "moma" and dev.type == "cuda"
                         and getattr(opt, "shuffle_bn", "per_rank") == "per_rank")
 

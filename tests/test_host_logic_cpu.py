@@ -100,3 +100,18 @@ def test_hip_env_switch_is_set_at_import_and_respects_the_caller():
     env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout.split()
     assert out == ["1", "False"]
+
+
+def test_loop_refuses_the_dual_queue_memories_up_front():
+    """--mem MoCoST / MoCoSSTT: the reference's loop passes (q, k, all_k) to every memory (helper/loops_moma.py:331) and dies in its
+    first step on these two (no k_t is ever computed).  Here the step object says so when it is built, before any compute."""
+    import argparse
+    import pytest
+    import torch
+    from moma_amd.helper.loops_moma import MomaStep
+
+    class Dual:
+        memory_s = None
+    with pytest.raises(NotImplementedError, match="k_t"):
+        MomaStep([None, None], [None, None, None], None, Dual(), None, argparse.Namespace(distill="moma"), torch.device("cpu"))
+    MomaStep([None, None], [None, None, None], None, Dual(), None, argparse.Namespace(distill="kd"), torch.device("cpu"))   # (kd: no memory used)
