@@ -376,6 +376,9 @@ def main_worker(gpu, ngpus_per_node, opt):
         save_state["Total params"] = sum(p.numel() for p in model_s.parameters()) / 1e6
         save_state["Total time"] = (time.time() - t_total) / 3600.0
         save_dict_to_json(save_state, os.path.join(opt.save_folder, "parameters.json"))
+    if opt.multiprocessing_distributed and torch.distributed.is_initialized():
+        torch.distributed.barrier()                             # (rank 0 has written its files before any rank tears the group down)
+        torch.distributed.destroy_process_group()
 
 
 def main(argv=None):
