@@ -130,8 +130,11 @@ class StepGraphs:
             return None
         key = self._key(images, labels)
         cap = self.graphs.get(key)
+        last, self._last_key = getattr(self, "_last_key", None), key
         if cap is None:
-            n = self.seen.get(key, 0) + 1
+            # CONSECUTIVE sightings count: the variant that opens every epoch (teacher still in eval mode) comes once per epoch and
+            # must never earn a capture of its own -- a second set of graph pools (13 GB reserved at B = 256) for one step per epoch
+            n = (self.seen.get(key, 0) if key == last else 0) + 1
             if len(self.seen) < 64 or key in self.seen:
                 self.seen[key] = n
             if n <= self.warmup or len(self.graphs) >= self.max_graphs:

@@ -52,7 +52,7 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
     torch.cuda.synchronize()
     sg = getattr(trainer, "_step_graphs", None)
     return dict(loss=torch.stack([t[0] for t in opt.trace]).cpu().numpy(), loss_kd=torch.stack([t[2] for t in opt.trace]).cpu().numpy(),
-                index=[t[1] for t in opt.trace], memory=contrast.memory.float().cpu().numpy(), replays=0 if sg is None else sg.replays,
+                index=[t[1] for t in opt.trace], memory=contrast.memory.float().cpu().numpy(), replays=0 if sg is None else sg.replays, ngraphs=0 if sg is None else len(sg.graphs),
                 student={k: v.float().cpu().numpy() for k, v in ms.state_dict().items()},
                 teacher={k: v.float().cpu().numpy() for k, v in mt.state_dict().items()},
                 atts_q=kd.atts_q.proj.weight.detach().cpu().numpy(), next_perm=torch.randperm(16).tolist(),
@@ -263,3 +263,16 @@ def test_a_runtime_that_fails_the_replay_self_test_keeps_the_eager_loop():
     assert a["replays"] == 0 and b["replays"] == 0
     assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"]
     np.testing.assert_allclose(a["loss"], b["loss"], rtol=2e-4, atol=2e-4)
+
+
+def test_the_once_per_epoch_variant_never_earns_a_capture():
+    """The step that opens every epoch (teacher in eval mode, reference helper/loops_moma.py:227) is a variant of its own: seen
+    once per epoch, it must stay eager however many epochs pass (a capture costs a second set of graph pools -- 13 GB reserved at
+    the bench shape).  Six epochs: one variant captured, five steps replayed in each epoch after the first."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(True, "resnet8", True, "bf16", "bf16", None, epochs=6, steps=6)
+    from moma_amd.helper import step_graph  # noqa: F401
+    assert a["ngraphs"] == 1
+    assert a["replays"] == 2 + 5 * 5           # epoch 1: steps 5-6; epochs 2-6: steps 2-6 (the ragged batch and each first step eager)
+    assert np.isfinite(a["loss"]).all()
