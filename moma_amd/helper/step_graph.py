@@ -137,11 +137,22 @@ class StepGraphs:
             n = (self.seen.get(key, 0) if key == last else 0) + 1
             if len(self.seen) < 64 or key in self.seen:
                 self.seen[key] = n
-            if n <= self.warmup or len(self.graphs) >= self.max_graphs:
+            if n <= self.warmup:
                 return None
+            if len(self.graphs) >= self.max_graphs:
+                # at capacity: the variant that has gone unused longest makes room (a variant keyed on a queue storage that was
+                # replaced since -- .cuda(), load_state_dict, a new `memory` -- can never match again; holding on to it would
+                # leave every later variant eager for good).  Its graphs are idle by now (this variant has just run `warmup`
+                # eager steps); the synchronize makes that a fact before they are destroyed.
+                torch.cuda.synchronize(images.device)
+                victim = min(self.graphs, key=lambda k_: self.graphs[k_].last_used)
+                del self.graphs[victim]
+                self.seen.pop(victim, None)
+                gc.collect()
             cap = self._capture(key, images, labels)
             if cap is None:
                 return None
+        cap.last_used = self.replays
         return self._replay(cap, images, labels)
 
     def _replay(self, cap, images, labels):

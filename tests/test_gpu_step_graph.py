@@ -157,6 +157,15 @@ def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
     rows = [(idx0 + i) % K for i in range(7 * B)]
     untouched = [r for r in range(K) if r not in set(rows)]
     assert torch.equal(contrast.memory[untouched], before[untouched]) and not torch.equal(contrast.memory[rows], before[rows])
+    # a THIRD storage: the runner is at capacity (max_graphs = 2) -- the variant unused longest (the first queue's, which can never
+    # match again) makes room instead of leaving every later variant eager for good
+    contrast.memory = torch.nn.functional.normalize(torch.randn(K, d, device=dev)).to(torch.bfloat16)
+    idx0 = contrast.index
+    opt.trace.clear()
+    train_distill_moma(4, [batch() for _ in range(7)], mods, crits, trainer, contrast, optimizer, opt)
+    assert len(sg.graphs) == 2 and sg.replays == 9 + 3
+    assert [t[1] for t in opt.trace] == [(idx0 + (i + 1) * B) % K for i in range(7)]
+    assert all(torch.isfinite(t[0]) for t in opt.trace)
 
 
 # ---- helper/graphs.py: the capture hazards of round 3 ------------------------------------------------------
