@@ -147,6 +147,29 @@ def test_two_rank_data_parallel(tmp_path, shuffle_mode, dp):
     assert r0["red"] == r1["red"] and abs(r0["red"][1] - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
 
 
+@pytest.mark.parametrize("shuffle_mode", ["per_rank", "gather"])
+def test_four_rank_data_parallel(tmp_path, shuffle_mode):
+    """The same at world size 4 (the driver's N = 4 step of the scaling run): replicas identical on every rank, per-rank queues
+    pairwise different / gathered queues equal, pointer arithmetic with the global batch in gather mode, metrics averaged over 4."""
+    world, port = 4, _free_port()
+    mp.spawn(_worker, args=(world, port, shuffle_mode, str(tmp_path), "flat"), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"r{i}.pt") for i in range(world)]
+    B, K = 4, 24
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["student"], r["student"])
+        assert torch.allclose(rs[0]["atts_q"], r["atts_q"], atol=1e-7) and torch.allclose(rs[0]["embed_s"], r["embed_s"], atol=1e-7)
+        assert torch.allclose(rs[0]["teacher"], r["teacher"], atol=1e-7)
+        assert r["red"] == rs[0]["red"]
+    n_enq = B if shuffle_mode == "per_rank" else B * world
+    assert all(r["index"] == (3 * n_enq) % K for r in rs)
+    if shuffle_mode == "per_rank":
+        assert all(not torch.equal(rs[i]["memory"], rs[j]["memory"]) for i in range(world) for j in range(i))
+    else:
+        assert all(torch.allclose(rs[0]["memory"], r["memory"], atol=1e-6) for r in rs[1:])
+        assert rs[0]["all_k_shape"] == (B * world, 32)
+    assert abs(rs[0]["red"][1] - sum(r["loss"] for r in rs) / world) < 1e-5
+
+
 def test_gather_mode_matches_reference_at_world_size_2(tmp_path, golden_dir):
     """n3 pinned to the REFERENCE at W = 2 (G9: learning/contrast_trainer.py:90-187 + MoMA/mem_moco.py:77-100 captured on two gloo
     ranks): `--shuffle_bn gather` -- image all_gather, id broadcast, teacher on the shuffled local share, key all_gather,
