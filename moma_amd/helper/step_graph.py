@@ -121,6 +121,7 @@ class StepGraphs:
         #  for it, and a replaced `memory` -- .cuda(), load_state_dict -- must not meet buffers of another shape)
         return (tuple(images.shape), images.dtype, images.is_contiguous(), tuple(labels.shape), labels.dtype,
                 hash(tuple(m.training for m in self._mods)), st.contrast.memory.data_ptr(), self._streamed_queue().data_ptr(),
+                tuple(st.contrast.memory.shape), st.contrast.memory.dtype,       # (a new queue may land on a freed queue's address)
                 st.contrast.T, st.amp_dtype, st.overlap, float(st.opt.cls), float(st.opt.div), float(st.opt.beta),
                 float(st.opt.alpha))
 
