@@ -107,6 +107,8 @@ class StepGraphs:
         from .loops_moma import _unwrap
         self._mods = list(_unwrap(st.model_s).modules()) + list(st.model_t.modules()) + list(st.criterion_kd.modules())
         self._bn = [m for m in self._mods if hasattr(m, "_nbt_pending")]
+        # every tensor the captured graphs read or write in place: parameters and buffers of the three module trees
+        self._state = [t for m in (_unwrap(st.model_s), st.model_t, st.criterion_kd) for t in list(m.parameters()) + list(m.buffers())]
 
     def _streamed_queue(self):
         """the tensor K2 streams: `memory`, or the bf16 mirror of an fp32 `memory` under the bf16 policy (made here if absent)"""
@@ -122,6 +124,9 @@ class StepGraphs:
         return (tuple(images.shape), images.dtype, images.is_contiguous(), tuple(labels.shape), labels.dtype,
                 hash(tuple(m.training for m in self._mods)), st.contrast.memory.data_ptr(), self._streamed_queue().data_ptr(),
                 tuple(st.contrast.memory.shape), st.contrast.memory.dtype,       # (a new queue may land on a freed queue's address)
+                # the graphs hold ADDRESSES of parameters and buffers: a tensor that moved (.to(), .half(), a re-created module
+                # attribute) makes this another variant -- never a replay through a stale pointer (~0.1 ms of host time per step)
+                hash(tuple(t.data_ptr() for t in self._state)),
                 st.contrast.T, st.amp_dtype, st.overlap, float(st.opt.cls), float(st.opt.div), float(st.opt.beta),
                 float(st.opt.alpha))
 

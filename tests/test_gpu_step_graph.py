@@ -285,3 +285,56 @@ def test_the_once_per_epoch_variant_never_earns_a_capture():
     assert a["ngraphs"] == 1
     assert a["replays"] == 2 + 5 * 5           # epoch 1: steps 5-6; epochs 2-6: steps 2-6 (the ragged batch and each first step eager)
     assert np.isfinite(a["loss"]).all()
+
+
+def test_a_moved_parameter_is_never_replayed_through_its_old_address():
+    """The captured graphs hold the addresses of parameters and buffers.  A tensor that moves between two steps (here: one student
+    weight re-created with the same values) must make the next steps another variant -- eager, then captured anew -- never a replay
+    through the stale pointer: the run continues exactly as the eager loop does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd.backbones import model_dict
+    from moma_amd.MoMA.mem_moco import build_mem
+    from moma_amd.MoMA.criterion_moco_att import CMO
+    from moma_amd.learning.contrast_trainer import ContrastTrainer
+    from moma_amd.helper.loops_moma import train_distill_moma
+    from moma_amd.distiller_zoo import DistillKL
+
+    def run(graph_student):
+        torch.backends.cudnn.benchmark = False
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(1)
+        B, K, d = 8, 128, 64
+        opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
+                                 cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
+                                 batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
+                                 moma_fused=True, trace=[], overlap_teacher=True, graph_student=graph_student)
+        ms, mt = model_dict["resnet8"](num_classes=10).to(dev), model_dict["resnet8"](num_classes=10).to(dev)
+        contrast, kd = build_mem(opt).to(dev), CMO(opt).to(dev)
+        trainer = ContrastTrainer(opt)
+        trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+        optimizer = torch.optim.SGD(trainable.parameters(), lr=0.02, momentum=0.0, weight_decay=0.0)
+        mods, crits = nn.ModuleList([ms, kd.embed_s, kd.embed_t, mt]), nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
+        gen = torch.Generator().manual_seed(3)
+        batch = lambda: (torch.randn(B, 3, 32, 32, generator=gen), torch.randint(0, 10, (B,), generator=gen))
+        torch.manual_seed(5)
+        train_distill_moma(1, [batch() for _ in range(7)], mods, crits, trainer, contrast, optimizer, opt)
+        # move one weight: a new tensor with the same values, registered under the same name (and known to the optimizer)
+        name, old = next((n, p) for n, p in ms.named_parameters() if p.dim() == 4)
+        new = nn.Parameter(old.detach().clone())
+        holder = ms
+        for part in name.split(".")[:-1]:
+            holder = getattr(holder, part)
+        setattr(holder, name.split(".")[-1], new)
+        for g in optimizer.param_groups:
+            g["params"] = [new if p is old else p for p in g["params"]]
+        del old
+        train_distill_moma(2, [batch() for _ in range(7)], mods, crits, trainer, contrast, optimizer, opt)
+        sg = getattr(trainer, "_step_graphs", None)
+        return (torch.stack([t[0] for t in opt.trace]).cpu().numpy(), 0 if sg is None else sg.replays,
+                0 if sg is None else len(sg.graphs), [t[1] for t in opt.trace])
+    lg, replays, ngraphs, idx_g = run(True)
+    le, none, _, idx_e = run(False)
+    assert replays == 3 + 3 and ngraphs == 2 and none == 0       # epoch 1: steps 5-7; epoch 2: warm-up of the new variant, then steps 5-7
+    assert idx_g == idx_e
+    np.testing.assert_allclose(lg, le, rtol=2e-4, atol=2e-4)
