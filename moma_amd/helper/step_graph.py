@@ -128,7 +128,7 @@ class StepGraphs:
                 # attribute) makes this another variant -- never a replay through a stale pointer (~0.1 ms of host time per step)
                 hash(tuple(t.data_ptr() for t in self._state)),
                 st.contrast.T, st.amp_dtype, st.overlap, float(st.opt.cls), float(st.opt.div), float(st.opt.beta),
-                float(st.opt.alpha))
+                float(st.opt.alpha), float(getattr(st.criterion_div, "T", 0.0)))
 
     # ---- one step ---------------------------------------------------------------------------------------------------------
     def step(self, images, labels):
