@@ -83,6 +83,7 @@ class GraphedInference:
         self._seen = {}
         self._graphs = {}
         self._mods = list(module.modules())
+        self._state = list(module.parameters()) + list(module.buffers())     # the graph reads these in place: their addresses are part of the key
 
     # the wrapped module stays reachable for everything that is not a forward call
     def __getattr__(self, name):
@@ -94,7 +95,7 @@ class GraphedInference:
         # the stream is part of the key: a graph is only ever replayed on the stream that captured it (library workspaces --
         # hipBLASLt, MIOpen -- belong to the capturing stream; see prime())
         stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
-        return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes, stream)
+        return (tuple(x.shape), x.dtype, x.device, x.is_contiguous(), bool(is_feat), ac, modes, hash(tuple(t.data_ptr() for t in self._state)), stream)
 
     def __call__(self, x, is_feat=False, full_feats=False):
         if full_feats:
