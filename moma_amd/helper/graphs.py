@@ -72,8 +72,8 @@ class GraphedInference:
     (pooled) feature, cloned, and the cloned logits; the intermediate feature maps live in the graph's static memory,
     are overwritten by the next replay and are therefore not handed out (the MoMA loop reads `feat[-1]` and the logits
     only; a caller that needs the whole list passes `full_feats=True` and gets an eager forward).  At most `max_graphs`
-    (shape, autocast, train/eval) variants are captured -- each holds a private activation pool; further variants (a
-    ragged last batch, another image size) run eagerly."""
+    (shape, autocast, train/eval, weight addresses, stream) variants are held -- each owns a private activation pool; at capacity
+    the one unused longest makes room for a new one."""
 
     def __init__(self, module, warmup: int = 3, max_graphs: int = 4):
         self.module = module
@@ -82,6 +82,7 @@ class GraphedInference:
         self.enabled = os.environ.get("MOMA_GRAPH_TEACHER", "1") == "1"
         self._seen = {}
         self._graphs = {}
+        self._used, self._tick = {}, 0
         self._mods = list(module.modules())
         self._state = list(module.parameters()) + list(module.buffers())     # the graph reads these in place: their addresses are part of the key
 
@@ -108,14 +109,22 @@ class GraphedInference:
             n = self._seen.get(key, 0) + 1
             if len(self._seen) < 64 or key in self._seen:
                 self._seen[key] = n
-            if n <= self.warmup or len(self._graphs) >= self.max_graphs:
-                if n > self.warmup and not getattr(self, "_cap_notice", False):
-                    self._cap_notice = True
-                    print(f"[moma] GraphedInference: {self.max_graphs} variants captured (each per stream); further variants stay eager")
+            if n <= self.warmup:
                 return self._trim(self.module(x, is_feat=is_feat), is_feat)
+            if len(self._graphs) >= self.max_graphs:
+                # at capacity: the variant unused longest makes room (one keyed on weights that have moved since can never match
+                # again); its graph is idle -- this variant has just been served `warmup` eager calls -- and the synchronize makes
+                # that a fact before it is destroyed
+                torch.cuda.synchronize(x.device)
+                victim = min(self._graphs, key=lambda k_: self._used.get(k_, 0))
+                del self._graphs[victim]
+                self._used.pop(victim, None)
+                self._seen.pop(victim, None)
             entry = self._capture(key, x, is_feat)
             if entry is None:
                 return self._trim(self.module(x, is_feat=is_feat), is_feat)
+        self._tick += 1
+        self._used[key] = self._tick
         graph, static_x, out, bn_train = entry
         static_x.copy_(x)
         graph.replay()

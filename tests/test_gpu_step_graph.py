@@ -338,3 +338,24 @@ def test_a_moved_parameter_is_never_replayed_through_its_old_address():
     assert replays == 3 + 3 and ngraphs == 2 and none == 0       # epoch 1: steps 5-7; epoch 2: warm-up of the new variant, then steps 5-7
     assert idx_g == idx_e
     np.testing.assert_allclose(lg, le, rtol=2e-4, atol=2e-4)
+
+
+def test_graphed_inference_makes_room_at_capacity():
+    """At `max_graphs` variants the one unused longest is dropped for a new one (a variant keyed on weights that moved can never
+    match again): five input shapes through a wrapper that holds two graphs -- every shape ends up served from a graph, results
+    equal the plain module."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from moma_amd.helper.graphs import GraphedInference
+    dev = torch.device("cuda", 0)
+    net = _small_net(dev)
+    g = GraphedInference(net, warmup=1, max_graphs=2)
+    with torch.no_grad():
+        for bs in (2, 3, 4, 5, 6):
+            x = torch.randn(bs, 3, 32, 32, device=dev)
+            ref = net(x, is_feat=True)[1]
+            outs = [g(x, is_feat=True)[1] for _ in range(3)]        # eager, capture + replay, replay
+            assert len(g._graphs) <= 2 and g._key(x, True) in g._graphs
+            for o in outs:
+                assert torch.allclose(o, ref, rtol=1e-4, atol=1e-4)
+    torch.cuda.synchronize()
