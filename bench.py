@@ -287,43 +287,96 @@ def heartbeat(period=60.0):
     threading.Thread(target=run, daemon=True).start()
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, counted WITHOUT any HIP / HSA call (the parent of the ranks must never open the device:
+    torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is unusable, as it is on this pool): KFD's topology in
+    sysfs -- a node with simd_count > 0 is a GPU --, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    when set.  None = unknown (no KFD sysfs): the ranks report a missing device themselves."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    have = 0
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            continue                                  # (a node this cgroup may not read is not ours)
+        if int(props.get("simd_count", "0")) > 0:
+            # (a container sees the host's whole topology; a GPU is ours when its render node is there and may be opened)
+            minor = props.get("drm_render_minor")
+            if minor is None or os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK):
+                have += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (one process per
-    GPU, rendezvous on 127.0.0.1) -- the reference's entry point spawns its own ranks too (train_student_moma.py:215-224,
-    mp.spawn).  This parent never touches the GPU; it relays the children's stderr, prints rank 0's JSON line and returns
-    their exit code (non-zero if any rank failed)."""
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script directly (one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, rendezvous on 127.0.0.1) -- the reference's entry
+    point spawns its own ranks too (train_student_moma.py:215-224, mp.spawn).  No torch.distributed.run in between: its launcher
+    process opens the device (LaunchConfig asks torch.cuda.is_available()), one more process on the card per job.  This parent
+    never touches the GPU (devices are counted from sysfs); it relays the children's stderr, prints rank 0's JSON line and
+    returns non-zero if any rank failed (the others are then terminated: they would wait in a collective forever)."""
     import socket
     import subprocess
     if os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1":
-        have = torch.cuda.device_count()            # (counts devices without initialising the runtime)
-        if have < n:
+        have = visible_gpu_count()
+        if have is not None and have < n:
             log(f"--gpus {n} but only {have} GPU(s) visible")
             return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's intra-node transport needs on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    base = dict(os.environ)
+    base.pop("MOMA_BENCH_SELF_LAUNCH", None)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+    base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     log(f"no launcher in the environment: starting {n} ranks: {' '.join(cmd)}")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)       # stderr is inherited (progress lines stream through)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    for l in r.stdout.splitlines():
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        # rank 0's stdout carries the JSON line; the other ranks' stdout joins the inherited stderr (progress lines stream through)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    reader.start()
+    code, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc
+                log(f"rank {r} exited with code {rc}; terminating the other ranks")
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    lines = [l for l in out0 if l.startswith("{")]
+    for l in out0:
         if not l.startswith("{"):
             print(l, file=sys.stderr)
-    if r.returncode != 0 or not lines:
-        log(f"launcher exited with code {r.returncode}{'' if lines else ' and no JSON line'}")
-        return r.returncode or 1
+    if code != 0 or not lines:
+        log(f"ranks exited with code {code}{'' if lines else ' and no JSON line'}")
+        return code or 1
     print(lines[-1], flush=True)
     return 0
 
 
 def main():
     a = parse()
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+    # (MOMA_BENCH_SELF_LAUNCH=1: also --gpus 1 goes through the parent path -- how the one-GPU box rehearses the exact code of --gpus N)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("MOMA_BENCH_SELF_LAUNCH") == "1"):
         raise SystemExit(launch_ranks(a.gpus))       # before any GPU call in this process
     heartbeat()
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -142,10 +142,11 @@ def _free_port():
     return port
 
 
-# (learning rate 0.01: at the bench's 0.05 this 32-sample / 64-pixel miniature is chaotic -- the loss after five steps differs by
-#  +-0.6 from run to run -- and once in a while diverges to NaN, which bench.py rightly refuses to report)
-_SMALL = ["--steps", "6", "--warmup", "5", "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline",
-          "--learning_rate", "0.01"]
+# (the bench's own learning rate, 0.05.  Round 4 ran these at 0.01 after one graph-served rehearsal ended in NaN; the cause found an
+#  hour later was the runtime's graph packet capture dropping captured memset nodes -- garbage bias gradients of nn.Linear layers,
+#  moma_amd/hip_env.py + helper/graphs.py:replay_is_safe() -- not the miniature's learning rate, so the guard is back on the
+#  configuration that failed.)
+_SMALL = ["--steps", "6", "--warmup", "5", "--batch_size", "32", "--image_size", "64", "--nce_k", "4096", "--no_cpu_baseline"]
 
 
 def _check_two_rank_line(out, dp, steps=6, warmup=5):
@@ -200,6 +201,33 @@ def test_bench_gpus2_without_a_launcher(tmp_path):
     assert len(lines) == 1 and lines[0].startswith("{"), lines          # stdout carries exactly the one JSON line
     _check_two_rank_line(json.loads(lines[0]), "flat")
     assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_self_launch_parent_path_on_one_rccl_rank(tmp_path):
+    """The code `python bench.py --gpus N` runs on the driver's 8-GPU node, with the one rank a one-GPU box allows and NO
+    MOMA_BENCH_SAME_DEVICE: the parent counts devices from sysfs (never through HIP), starts the rank itself (no
+    torch.distributed.run in between) and relays its JSON line; the rank initialises RCCL ("nccl") from the env:// variables the
+    parent set and runs the N > 1 step (flat wrap, step graphs, side stream).  MOMA_BENCH_SELF_LAUNCH=1 sends --gpus 1 down
+    that path; MOMA_BENCH_FORCE_DIST=1 makes the one rank build its process group."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOMA_DP", "MOMA_BENCH_SAME_DEVICE",
+                                                            "MOMA_BENCH_BACKEND")}
+    env.update(MOMA_BENCH_SELF_LAUNCH="1", MOMA_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + _SMALL, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["dist"]["backend"] == "nccl" and out["dist"]["world_size"] == 1
+    assert out["dist"]["dp_wrap"] == "FlatDataParallel" and np.isfinite(out["loss_mean_timed_steps"])
+    assert out["config"]["step_graphs"]["timed_steps_replayed"] >= 4, out["config"]["step_graphs"]
+    assert "starting 1 ranks" in r.stderr and "torch.distributed.run" not in r.stderr.split("starting 1 ranks")[1].splitlines()[0]
+    # and more ranks than the box has GPUs is refused by the parent, from sysfs, before anything starts
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + _SMALL, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env={k: v for k, v in env.items() if not k.startswith("MOMA_BENCH")})
+    assert r.returncode == 2 and "only 1 GPU(s) visible" in r.stderr, (r.returncode, r.stderr[-2000:])
 
 
 def test_bench_refuses_a_non_finite_loss(tmp_path):

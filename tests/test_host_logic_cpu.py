@@ -115,3 +115,92 @@ def test_loop_refuses_the_dual_queue_memories_up_front():
     with pytest.raises(NotImplementedError, match="k_t"):
         MomaStep([None, None], [None, None, None], None, Dual(), None, argparse.Namespace(distill="moma"), torch.device("cpu"))
     MomaStep([None, None], [None, None, None], None, Dual(), None, argparse.Namespace(distill="kd"), torch.device("cpu"))   # (kd: no memory used)
+
+
+def _launch_with_children(monkeypatch, n, child_code, argv=("--gpus", "2")):
+    """Run bench.launch_ranks(n) with every rank replaced by `python -c child_code` (real processes, pipes and exit codes) and
+    with every way of counting devices through HIP turned into an error."""
+    import subprocess
+    import sys
+    import bench
+
+    def refuse(*a, **k):
+        raise AssertionError("the parent of the ranks asked the HIP runtime for devices")
+    monkeypatch.setattr(torch._C, "_cuda_getDeviceCount", refuse)
+    monkeypatch.setattr(torch.cuda, "device_count", refuse)
+    monkeypatch.setattr(torch.cuda, "is_available", refuse)
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: n)
+    monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+    real, seen = subprocess.Popen, []
+
+    def popen(cmd, **kw):
+        seen.append((cmd, kw["env"]))
+        return real([sys.executable, "-c", child_code], **kw)
+    monkeypatch.setattr(subprocess, "Popen", popen)
+    rc = bench.launch_ranks(n)
+    assert not torch.cuda.is_initialized()
+    return rc, seen
+
+
+def test_launch_ranks_parent_stays_off_the_gpu_and_starts_the_ranks_itself(monkeypatch, capfd):
+    """bench.py --gpus N without a launcher (ADVICE r4 / VERDICT r4 item 5): the parent counts devices from sysfs only, starts the
+    N ranks directly (no torch.distributed.run, whose launcher opens the device) with the rendezvous variables torch.distributed's
+    env:// init reads, relays rank 0's one JSON line, and returns 0."""
+    import json
+    import os
+    code = ("import os, json; r = os.environ['RANK']; print('progress from rank', r); "
+            "print(json.dumps({k: os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}))")
+    rc, seen = _launch_with_children(monkeypatch, 3, code, argv=("--gpus", "3", "--steps", "2"))
+    out, err = capfd.readouterr()
+    assert rc == 0 and len(seen) == 3
+    for r, (cmd, env) in enumerate(seen):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "3", "--steps", "2"] and "torch.distributed.run" not in cmd
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "3", "127.0.0.1")
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        assert "MOMA_BENCH_SELF_LAUNCH" not in env
+    assert len({env["MASTER_PORT"] for _, env in seen}) == 1
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["RANK"] == "0"          # stdout = rank 0's JSON line, nothing else
+    assert "progress from rank 0" in err and "progress from rank 2" in err
+
+
+def test_launch_ranks_a_failed_rank_ends_the_job(monkeypatch, capfd):
+    """One rank dies: the others (which would wait in a collective forever) are terminated and the parent reports the failure."""
+    import time
+    code = "import os, sys, time; sys.exit(5) if os.environ['RANK'] == '1' else time.sleep(600)"
+    t0 = time.time()
+    rc, _ = _launch_with_children(monkeypatch, 2, code)
+    assert rc == 5 and time.time() - t0 < 60
+    assert "rank 1 exited with code 5" in capfd.readouterr().err
+
+
+def test_launch_ranks_refuses_more_ranks_than_gpus(monkeypatch):
+    import bench
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
+    monkeypatch.delenv("MOMA_BENCH_SAME_DEVICE", raising=False)
+    assert bench.launch_ranks(2) == 2
+
+
+def test_visible_gpu_count_reads_sysfs_and_the_visibility_masks(monkeypatch, tmp_path):
+    """KFD topology: nodes with simd_count > 0 are GPUs (CPU nodes have 0); *_VISIBLE_DEVICES narrow the count; no sysfs = None."""
+    import glob
+    import bench
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real = glob.glob
+    monkeypatch.setattr(glob, "glob", lambda pat: real(str(tmp_path / "*" / "properties")) if "kfd" in pat else real(pat))
+    # (no drm_render_minor line: counted; with one, the render node must exist and be accessible)
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count() == 3
+    with open(tmp_path / "4" / "properties", "a") as f:
+        f.write("drm_render_minor 99999\n")                     # a GPU of the host that this container was not given
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpu_count() == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2,3")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setattr(glob, "glob", lambda pat: [])
+    assert bench.visible_gpu_count() is None
