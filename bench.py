@@ -67,8 +67,10 @@ def parse():
     p.add_argument("--miopen_find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode)")
     p.add_argument("--no_graph_student", dest="graph_student", action="store_false",
                    help="issue the step launch by launch instead of replaying it from HIP graphs (helper/step_graph.py)")
-    p.add_argument("--no_prefetch_queue", dest="prefetch_queue", action="store_false",
-                   help="skip the side-stream sweep that warms the Infinity Cache with the queue ahead of K2 (experiment switch)")
+    p.add_argument("--prefetch_queue", action="store_true",
+                   help="experiment switch, OFF by default since round 5: a side-stream sweep that warms the Infinity Cache with the "
+                        "queue ahead of K2 -- a second read of the 67 MB queue per step (15 us beside the attention launches) that "
+                        "bought 0.6 us of the one-pass kernel (profiles/r04_step_kernel_stats.csv)")
     p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
                    help="queue the teacher / key side of the step on the main stream instead of a second HIP stream")
     return p.parse_args()

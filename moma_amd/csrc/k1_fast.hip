@@ -446,16 +446,36 @@ struct CoreFwdArgs {
     int N, d, H;
 };
 
+// Workgroup -> (32-row block, head, z = module / role) on a 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (ids b and
+// b + 8 share one), each with its own L2, and what the workgroups of a core launch re-read is per (head, z): the head's K / V (or
+// dA / Q) columns of qkv16.  With the plain order (32-row block fastest) the 8 row blocks of a head land on 8 different XCDs and every
+// XCD pulls every head's operands through its own cold L2 (round 4 counters: 6.0 MB fetched for 0.77 MB of distinct bytes, 10 % L2
+// hits).  Here XCD x takes a CONTIGUOUS range of the (z, head, block) order -- at N = 256, H = 4: one or two (head, z) pairs per
+// XCD.  Speed only: any placement is correct.  (total % 8 != 0: the plain order.)
+struct CoreBlock { int blk, head, z; };
+__device__ __forceinline__ CoreBlock core_block(int N, int H) {
+    const int nb = (N + 31) >> 5, total = gridDim.x;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+    CoreBlock c;
+    c.blk = L % nb;
+    const int g = L / nb;
+    c.head = g % H;
+    c.z = g / H;
+    return c;
+}
+
 // FULL: head dim 128 (every k-step and column tile of the images is live: no guards in the MFMA chains)
 template <bool ONE_TILE, bool FULL>
 __global__ __launch_bounds__(NW * 64) void k1_core_fwd_kernel(CoreFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const CoreMod M = a.m[blockIdx.z];
     const int N = a.N, d = a.d, hd = d / a.H;
+    const CoreBlock cb = core_block(N, a.H);
+    const CoreMod M = a.m[cb.z];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h2 = lane >> 5;
-    const int head = blockIdx.y, q0 = blockIdx.x * 32;
+    const int head = cb.head, q0 = cb.blk * 32;
     const long ld = 3L * d;
     const int nch = FULL ? 16 : hd >> 3, kse = FULL ? 8 : hd >> 4, nct = FULL ? 4 : (hd + 31) >> 5;
     const bf16_raw* qb = M.qkv + head * hd;
@@ -605,12 +625,13 @@ __global__ __launch_bounds__(NW * 64) void k1_core_fwd_kernel(CoreFwdArgs a) {
 template <int TW>
 __global__ __launch_bounds__(NW * 64) void k1_core_fwd_wide_kernel(CoreFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const CoreMod M = a.m[blockIdx.z];
     const int N = a.N, d = a.d, hd = d / a.H;
+    const CoreBlock cb = core_block(N, a.H);
+    const CoreMod M = a.m[cb.z];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h2 = lane >> 5;
-    const int head = blockIdx.y, q0 = blockIdx.x * 32;
+    const int head = cb.head, q0 = cb.blk * 32;
     const long ld = 3L * d;
     const int nseg = (hd + 127) >> 7;
     const bf16_raw* qb = M.qkv + head * hd;
@@ -806,7 +827,8 @@ __device__ __forceinline__ void k1_core_bwd_role(char* smem, const CoreBwdArgs& 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h2 = lane >> 5;
-    const int head = blockIdx.y, b0 = blockIdx.x * 32;
+    const CoreBlock cb = core_block(N, a.H);
+    const int head = cb.head, b0 = cb.blk * 32;
     const long ld = 3L * d;
     const int nch = FULL ? 16 : hd >> 3, kse = FULL ? 8 : hd >> 4, nct = FULL ? 4 : (hd + 31) >> 5, npart = FULL ? 8 : hd >> 4;
     const bf16_raw* qb = a.qkv + head * hd;
@@ -941,7 +963,7 @@ __device__ __forceinline__ void k1_core_bwd_role(char* smem, const CoreBwdArgs& 
 template <bool FULL>
 __global__ __launch_bounds__(NW * 64) void k1_core_bwd_kernel(CoreBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.z == 0) k1_core_bwd_role<false, FULL>(smem, a);
+    if (core_block(a.N, a.H).z == 0) k1_core_bwd_role<false, FULL>(smem, a);
     else k1_core_bwd_role<true, FULL>(smem, a);
 }
 
@@ -958,7 +980,8 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h2 = lane >> 5;
-    const int head = blockIdx.y, b0 = blockIdx.x * 32;
+    const CoreBlock cb = core_block(N, a.H);
+    const int head = cb.head, b0 = cb.blk * 32;
     const long ld = 3L * d;
     const int nseg = (hd + 127) >> 7, npart = hd >> 4;
     const bf16_raw* qb = a.qkv + head * hd;
@@ -1117,7 +1140,7 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
 template <int TW>
 __global__ __launch_bounds__(NW * 64) void k1_core_bwd_wide_kernel(CoreBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (blockIdx.z == 0) k1_core_bwd_wide_role<false, TW>(smem, a);
+    if (core_block(a.N, a.H).z == 0) k1_core_bwd_wide_role<false, TW>(smem, a);
     else k1_core_bwd_wide_role<true, TW>(smem, a);
 }
 
@@ -1215,7 +1238,7 @@ hipError_t launch_mha_fwd_fast(const moma_mha_module_t* mods, int n_modules, int
     CoreFwdArgs ca{};
     ca.N = N; ca.d = d; ca.H = H;
     for (int i = 0; i < n_modules; ++i) ca.m[i] = CoreMod{(const bf16_raw*)mods[i].qkv16, (bf16_raw*)mods[i].attn16, mods[i].lse};
-    const dim3 grid((N + 31) / 32, H, n_modules), block(NW * 64);
+    const dim3 grid(((N + 31) / 32) * H * n_modules), block(NW * 64);      // 1-D: core_block() places the workgroups
     const bool one = N <= KT * NW, full = hd == 128;                                                       // (:159-163)
     const int tw = (N + KT * NW - 1) / (KT * NW);                  // key tiles per wave of the wide-head cores: 1 .. 4
     if (hd > 128 && tw <= 1) hipLaunchKernelGGL(k1_core_fwd_wide_kernel<1>, grid, block, CORE_LDS, st, ca);
@@ -1269,12 +1292,12 @@ hipError_t launch_mha_bwd_fast(const void* pack, const void* x, int x_dtype, con
     // launch 2: the per-head core
     CoreBwdArgs ca{(const bf16_raw*)qkv16, dA16, lse, dpart, dqkv16, N, d, H};
     const int tw = (N + KT * NW - 1) / (KT * NW);
-    if (d / H > 128 && tw <= 1) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<1>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<1>(), st, ca);
-    else if (d / H > 128 && tw == 2) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<2>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<2>(), st, ca);
-    else if (d / H > 128 && tw == 3) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<3>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<3>(), st, ca);
-    else if (d / H > 128) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<4>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), bwd_wide_lds<4>(), st, ca);
-    else if (d / H == 128) hipLaunchKernelGGL(k1_core_bwd_kernel<true>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
-    else hipLaunchKernelGGL(k1_core_bwd_kernel<false>, dim3((N + 31) / 32, H, 2), dim3(NW * 64), BWD_LDS, st, ca);
+    if (d / H > 128 && tw <= 1) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<1>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), bwd_wide_lds<1>(), st, ca);
+    else if (d / H > 128 && tw == 2) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<2>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), bwd_wide_lds<2>(), st, ca);
+    else if (d / H > 128 && tw == 3) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<3>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), bwd_wide_lds<3>(), st, ca);
+    else if (d / H > 128) hipLaunchKernelGGL(k1_core_bwd_wide_kernel<4>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), bwd_wide_lds<4>(), st, ca);
+    else if (d / H == 128) hipLaunchKernelGGL(k1_core_bwd_kernel<true>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), BWD_LDS, st, ca);
+    else hipLaunchKernelGGL(k1_core_bwd_kernel<false>, dim3(((N + 31) / 32) * H * 2), dim3(NW * 64), BWD_LDS, st, ca);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // launch 3: dWqkv = dqkv^T x, dbqkv = colsum(dqkv), dx = dqkv Wqkv

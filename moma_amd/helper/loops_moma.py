@@ -158,9 +158,11 @@ class MomaStep:
         return out
 
     def prefetch_queue(self):
-        """the queue was last read a whole step ago: sweep it into the Infinity Cache on the side stream while the
-        (launch-latency-bound) attention module runs on the main one; K2 then streams it at cache latency"""
-        if self.overlap and self.fused and getattr(self.opt, "prefetch_queue", True) and hasattr(self.contrast, "prefetch"):
+        """opt.prefetch_queue (default OFF since round 5): the queue was last read a whole step ago: sweep it into the Infinity
+        Cache on the side stream while the (launch-latency-bound) attention module runs on the main one.  Measured (round 4): the
+        sweep re-reads the whole queue (67 MB, 15 us on the side stream) to take 0.6 us off the one-pass kernel -- 2.5x the
+        algorithmic bytes of the KD term for nothing the step's time shows; kept as an experiment switch only."""
+        if self.overlap and self.fused and getattr(self.opt, "prefetch_queue", False) and hasattr(self.contrast, "prefetch"):
             self.contrast.prefetch(stream=self.side_stream())
 
     def forward_part(self, images, labels, teacher):

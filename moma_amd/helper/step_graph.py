@@ -7,7 +7,7 @@ captured ONCE into four HIP graphs and replayed, on the same two streams and wit
 
     side stream : g_teacher  teacher forward #1, K4 EMA, Shuffle-BN key encoding, K1 key side (all no-grad)
     main stream : g_student  the student's forward                                 -- concurrent with g_teacher
-                  (join)     main waits for the side stream; the queue prefetch is launched on the side stream
+                  (join)     main waits for the side stream (opt.prefetch_queue, off by default: a queue sweep on the side stream)
                   g_query    CE + KL, embed_s, K1 query side (leaves q packed for K2), the student's top-1
                   eager      K2 (one pass over the queue, into static buffers) + K3 (enqueue): the ring pointer stays the HOST
                              integer of the contract (a launch argument of a captured kernel is frozen, the pointer moves every
@@ -177,7 +177,7 @@ class StepGraphs:
                 cap.g_teacher.replay()
             cap.g_student.replay()
             main.wait_stream(side)
-            st.prefetch_queue()                            # (on the side stream, under the attention launches of g_query)
+            st.prefetch_queue()                            # (only with opt.prefetch_queue: on the side stream, under g_query)
         else:
             cap.g_student.replay()
             cap.g_teacher.replay()

@@ -25,7 +25,7 @@ run --feat_dim 128
 run --feat_dim 384 --num_heads 8
 run --no_graph_student
 run --no_overlap_teacher
-run --no_prefetch_queue
+run --prefetch_queue
 run --print_freq 1
 run --model resnet8x4
 run --model ResNet18 --image_size 64

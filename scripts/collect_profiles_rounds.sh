@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-4 additions to the rocprofv3 evidence (the round-3 set is scripts/collect_profiles.sh):
+# Round-4 and later additions to the rocprofv3 evidence (the round-3 set is scripts/collect_profiles.sh):
 #   K1: HBM / fabric traffic and L2 hit counters next to the SQ counters (the "cold L2" model of DESIGN.md, VERDICT r3 #6a)
 #   K2 wide rows: SQ + FETCH / WRITE passes for d = 1280 and d = 2048 (none existed for 2048; 1280 was round 2's)
 #   K2 small batch (B = 64: the reference's default --batch_size): kernel stats + SQ + FETCH / WRITE
 #   K2 exact-fp32 at d = 1280 (the segment-streamed one-pass kernel); the training step under the step graphs (B = 256 and 64)
-# usage (GPU box, repo root):  bash scripts/collect_profiles_r04.sh [sections]      sections: k1 k2 k2w k2x k2s k2f step step64   (default: all)
-TAG=r04
+# usage (GPU box, repo root):  bash scripts/collect_profiles_rounds.sh [sections]   (TAG=rNN in the environment names the round; default r05)      sections: k1 k2 k2w k2x k2s k2f step step64   (default: all)
+TAG=${TAG:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
