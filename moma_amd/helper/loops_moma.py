@@ -77,10 +77,14 @@ class MomaStep:
 
     def graphable(self):
         """What helper/step_graph.py captures: the bench / run-script configuration (--distill moma, one-pass K2, --attn self,
-        MoCo memory, per-rank Shuffle-BN, no GradScaler).  Everything else keeps the eager loop."""
+        MoCo memory, per-rank Shuffle-BN; fp16 + GradScaler when the optimizer takes the scale and the found-inf flag on the
+        device -- torch's fused SGD, what build_training makes for --amp fp16: the captured backward multiplies by the scaler's
+        device tensor, `scaler.step / update` stay eager behind the graphs and read nothing back).  Everything else keeps the
+        eager loop."""
         o = self.opt
+        scaler_ok = self.scaler is None or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
         return (self.dev.type == "cuda" and o.distill == "moma" and self.fused and not self.mocoatt and not self.attn_in_shuffle
-                and getattr(o, "attn", "self") == "self" and self.scaler is None and hasattr(self.contrast, "forward_fused_into")
+                and getattr(o, "attn", "self") == "self" and scaler_ok and hasattr(self.contrast, "forward_fused_into")
                 and getattr(o, "shuffle_bn", "per_rank") == "per_rank")
 
     def teacher_side(self, images, teacher):

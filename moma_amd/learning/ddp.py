@@ -21,8 +21,11 @@ What the stock wrap checks and this one has to check itself:
     sum all-reduce) on a known pattern and compares with the closed form.  `wrap_student(mode=None)` = "auto": flat when the
     self-test passes, the stock reducer (with a notice) when it does not;
   * every step: the set of gradients that goes into the flat buffer must be the same on every rank or the collective's sizes
-    differ (a hang, or silent corruption).  The (count, element total, index hash) of the set is exchanged whenever it CHANGES
-    on a rank (first step, a head un-frozen later) and a mismatch raises on every rank; an unchanged set costs nothing.
+    differ (a hang, or silent corruption).  The (count, element total, index hash) of the set is agreed on EVERY step, before
+    the flat all-reduce is issued, over a host-side control group (`control_group`: gloo, CPU tensors -- no GPU work, no stream
+    sync; ~0.1 ms of host time in a step whose host has tens of ms to spare): a MAX all-reduce of (sig, -sig), so max != min
+    raises on every rank alike.  (Round 4 exchanged it only when it changed on the LOCAL rank: a set that changed on one rank
+    alone sent that rank into an all_gather while the others entered the all-reduce -- ADVICE r4.)
 `wrap_student(..., mode="ddp")` (`--dp ddp`, `MOMA_DP=ddp`) keeps the stock reducer with the flat buffer broadcast.
 """
 from __future__ import annotations
@@ -66,6 +69,34 @@ def _all_agree(values, device, group=None, what="replicas"):
     rows = [g.tolist() for g in got]
     if any(r != rows[0] for r in rows):
         raise RuntimeError(f"data-parallel {what} differ across ranks (count, elements, layout hash per rank): {rows}")
+
+
+_control_groups = {}
+
+
+def control_group(group=None):
+    """Host-side agreement channel next to the data group: the group itself when it runs on gloo, else a gloo group over the same
+    ranks (made once per data group; COLLECTIVE: every rank of `group` must call it at the same point -- the wrap's constructor
+    and wrap_student do).  Carries a few int64 on CPU tensors: verdicts and fingerprints, never data."""
+    key = (id(group) if group is not None else None, id(dist.group.WORLD))      # (a re-initialised process group is another key)
+    if key not in _control_groups:
+        if dist.get_backend(group) == "gloo":
+            _control_groups[key] = group if group is not None else dist.group.WORLD
+        else:
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _control_groups[key]
+
+
+def _host_agree(values, ctl, what):
+    """every rank holds the same int64 vector, or RuntimeError on EVERY rank: MAX all-reduce of (v, -v) on the control group"""
+    v = torch.tensor(list(values) + [-x for x in values], dtype=torch.int64)
+    mine = v.clone()
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=ctl)
+    n = len(values)
+    if not torch.equal(v[:n], -v[n:]):                       # max != min somewhere: the same verdict on every rank
+        raise RuntimeError(f"data-parallel {what} differ across ranks: this rank holds {mine[:n].tolist()}, the ranks' maxima are "
+                           f"{v[:n].tolist()} and minima {(-v[n:]).tolist()} (count, elements, index hash)")
 
 
 def broadcast_module_state(modules, group=None):
@@ -132,7 +163,7 @@ class FlatDataParallel(nn.Module):
             _all_agree(_fingerprint(state), state[0].device, group, "student replicas")     # as DDP's constructor verifies
         _flat_broadcast(state, group)                                                        # replicas start from rank 0
         self.flat_buffer_broadcast = FlatBufferBroadcast(module, group)
-        self._grad_sig = None            # fingerprint of the gradient set the ranks last agreed on
+        self._ctl = control_group(group) if dist.get_world_size(group) > 1 else None     # (collective: all ranks construct the wrap)
         self.allreduce_launches = 0
 
     def forward(self, *args, **kwargs):
@@ -160,12 +191,9 @@ class FlatDataParallel(nn.Module):
             sig = (0, 0, 0)
         else:
             sig = (len(which), sum(params[i].grad.numel() for i in which), zlib.crc32(repr(which).encode()))
-        if sig != self._grad_sig:
-            # the set changed on THIS rank (first step; a module joined or left the backward): it must have changed on all of
-            # them, and to the same set -- otherwise the flat buffers differ in size
-            dev = params[which[0]].grad.device if which else next(self.module.parameters()).device
-            _all_agree(list(sig), dev, self.group, "gradient sets")
-            self._grad_sig = sig
+        if self._ctl is not None:
+            # agreed on every step, on the host, BEFORE the collective whose size depends on it
+            _host_agree(sig, self._ctl, "gradient sets")
         with ops._timed("dp_allreduce_grads"):
             for grads in by_kind.values():                      # (one group in practice: every gradient here is fp32)
                 flat = torch.cat([g.reshape(-1) for g in grads])
@@ -182,11 +210,18 @@ def wrap_student(model: nn.Module, device_ids=None, group=None, mode: str | None
     mode = mode or os.environ.get("MOMA_DP", "auto")
     if mode == "auto":
         dev = next(model.parameters()).device
+        ctl = control_group(group) if dist.get_world_size(group) > 1 else None
         try:
             ok = collective_self_test(dev, group)
         except Exception as e:                                   # a backend that cannot run one of the two collectives
             print(f"[moma] flat data-parallel self-test raised {type(e).__name__}: {e}")
             ok = False
+        if ctl is not None:
+            # one verdict for all: a rank whose self-test RAISED (and never reached the test's own MIN all-reduce) must not end up
+            # under another wrap than the rest -- AND-ed on the host-side channel, outside the try
+            v = torch.tensor([1 if ok else 0], dtype=torch.int64)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=ctl)
+            ok = bool(v.item() == 1)
         mode = "flat" if ok else "ddp"
         if not ok and dist.get_rank() == 0:
             print("[moma] flat data-parallel self-test FAILED on this communicator: falling back to the stock DDP reducer")

@@ -195,8 +195,12 @@ def build_training(opt, device):
         raise NotImplementedError(opt.distill)
     criterion_list = nn.ModuleList([criterion_cls, criterion_div, criterion_kd])
     module_list.append(model_t)
+    # --amp fp16: the fused SGD takes GradScaler's scale and found-inf flag as DEVICE tensors (the update is skipped inside the
+    # kernel), so `scaler.step()` reads nothing back -- the stock path syncs the host once per step (`found_inf.item()`), which
+    # cost BASELINE configs[4] its run-ahead (round 4: 119 ms of host time in a 120 ms step) and kept the step out of HIP graphs
+    fused = getattr(opt, "amp", None) == "fp16" and torch.device(device).type == "cuda"
     optimizer = optim.SGD(trainable_list.parameters(), lr=opt.learning_rate, momentum=opt.momentum,
-                          weight_decay=opt.weight_decay)
+                          weight_decay=opt.weight_decay, **({"fused": True} if fused else {}))
     module_list.to(device)
     criterion_list.to(device)
     if getattr(opt, "channels_last", False):

@@ -327,18 +327,26 @@ def _safety_worker(rank, world, port, out):
         res["gradset_refused"] = False
     except RuntimeError as e:
         res["gradset_refused"] = "gradient sets differ" in str(e)
-    # (5) same set on both ranks: one collective, averaged; an unchanged set is not re-verified
+    # (5) same set on both ranks: one collective, averaged
     for p in params:
         p.grad = None
     (flat(x * (rank + 1)).sum() + extra(x * (rank + 1)).sum()).backward()
     local = [p.grad.clone() for p in params]
     res["n_coll"] = flat.allreduce_grads(params)
-    sig = flat._grad_sig
     gathered = [[torch.empty_like(g) for _ in range(world)] for g in local]
     for g, dst in zip(local, gathered):
         dist.all_gather(dst, g)
     res["avg_ok"] = all(torch.allclose(p.grad, sum(dst) / world, atol=1e-6) for p, dst in zip(params, gathered))
-    res["sig_kept"] = flat._grad_sig == sig and sig[0] == len(params)
+    # (6) AFTER the ranks have agreed once, the set changes on ONE rank only (round 4 re-verified only when the LOCAL
+    #     set changed, so rank 1 went into the exchange alone while rank 0 entered the all-reduce): refused on every rank, every time
+    for p in params:
+        p.grad = None
+    (flat(x).sum() + (extra(x).sum() if rank == 0 else 0.0)).backward()      # rank 0 keeps the agreed set, rank 1 loses `extra`
+    try:
+        flat.allreduce_grads(params)
+        res["late_change_refused"] = False
+    except RuntimeError as e:
+        res["late_change_refused"] = "gradient sets differ" in str(e)
     torch.save(res, f"{out}.rank{rank}")
     dist.barrier()
     dist.destroy_process_group()
@@ -353,5 +361,5 @@ def test_flat_wrap_safety_checks(tmp_path):
     r0, r1 = torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")
     for r in (r0, r1):
         assert r["self_test"] and r["auto_is_flat"] and r["layout_refused"] and r["gradset_refused"]
-        assert r["n_coll"] == 1 and r["avg_ok"] and r["sig_kept"]
+        assert r["n_coll"] == 1 and r["avg_ok"] and r["late_change_refused"]
     assert torch.equal(r0["state"], r1["state"]) and r0["state"][-11:-6].eq(1.0).all()     # rank 0's running_mean (rank 1 had 2.0); then var [5], count [1]

@@ -13,7 +13,7 @@ import torch.nn as nn
 pytestmark = pytest.mark.gpu
 
 
-def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02):
+def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -38,7 +38,11 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
     ms, mt, contrast, kd = ms.to(dev), mt.to(dev), contrast.to(dev), kd.to(dev)
     trainer = ContrastTrainer(opt)
     trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
-    optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    if amp == "fp16":            # as train_student_moma.build_training / main_worker do for --amp fp16
+        opt._grad_scaler = torch.amp.GradScaler("cuda", init_scale=scale0)
+        optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, fused=True)
+    else:
+        optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     student0 = torch.cat([p.detach().reshape(-1) for p in ms.parameters()]).clone()
     mods = nn.ModuleList([ms, kd.embed_s, kd.embed_t, mt])            # the CLI's module list with --head mlp
     crits = nn.ModuleList([nn.CrossEntropyLoss(), DistillKL(4.0), kd])
@@ -57,6 +61,7 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
                 teacher={k: v.float().cpu().numpy() for k, v in mt.state_dict().items()},
                 atts_q=kd.atts_q.proj.weight.detach().cpu().numpy(), next_perm=torch.randperm(16).tolist(),
                 delta=(torch.cat([p.detach().reshape(-1) for p in ms.parameters()]) - student0).double().cpu().numpy(),
+                scale=None if amp != "fp16" else float(opt._grad_scaler.get_scale()),
                 atts_k_grad_none=all(p.grad is None for p in kd.atts_k.parameters()),
                 grads_attached=all(p.grad is not None for p in ms.parameters()))
 
@@ -104,6 +109,32 @@ def test_step_graphs_equal_the_eager_loop(model, overlap, prec, queue_dtype, amp
             np.testing.assert_allclose(a["student"][name], b["student"][name], rtol=0, atol=20 * tol, err_msg=name)
             np.testing.assert_allclose(a["teacher"][name], b["teacher"][name], rtol=0, atol=20 * tol, err_msg=name)
     np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=20 * tol)
+
+
+@pytest.mark.parametrize("scale0", [2.0 ** 10, 2.0 ** 40])
+def test_step_graphs_with_fp16_and_a_grad_scaler(scale0):
+    """--amp fp16 (BASELINE configs[4]): fp16 autocast + GradScaler with the step served from HIP graphs -- the captured backward
+    starts from loss * scale (the scaler's DEVICE tensor, read at replay time), `scaler.step()` hands scale and found-inf to the
+    fused SGD as device tensors and `scaler.update()` adjusts the scale on the device: no host read-back anywhere, replays and
+    eager steps interleave.  Against the same run issued launch by launch: per-step losses, pointer, final scale (exact: the
+    same sequence of finite / overflowed steps).  scale0 = 2^40 overflows fp16 gradients for the first steps: those updates are
+    skipped INSIDE the optimizer kernel and the scale backs off -- on both paths alike, also across the capture."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(True, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0)
+    b = _run(False, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0)
+    assert a["replays"] == 3 + 6 and b["replays"] == 0 and a["ngraphs"] == 1
+    assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"]
+    assert a["scale"] == b["scale"] and (a["scale"] < scale0 if scale0 > 2.0 ** 30 else a["scale"] == scale0), (a["scale"], b["scale"])
+    assert np.isfinite(a["loss"]).all() and np.isfinite(b["loss"]).all()
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=5e-3, atol=5e-3)
+    assert a["loss"][0] == b["loss"][0] and np.linalg.norm(b["delta"]) > 0
+    rel = np.linalg.norm(a["delta"] - b["delta"]) / np.linalg.norm(b["delta"])
+    assert rel < 0.3, rel
+    for name in a["student"]:
+        if "num_batches_tracked" in name:
+            assert np.array_equal(a["student"][name], b["student"][name]) and a["student"][name] == 15, name
 
 
 def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
