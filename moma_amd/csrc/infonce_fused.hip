@@ -2036,12 +2036,23 @@ struct FlashPlan {
     int nbt, nchunk, tiles_per_chunk, Bpad;
 };
 
+// Workgroups a pass over the queue is cut into: one per compute unit.  MOMA_K2_TARGET_WG (read once) overrides it for plan sweeps
+// (scripts/sweep_k2_plan.sh); every caller of plan() -- workspace sizes included -- sees the same value for the process's life.
+int target_workgroups() {
+    static const int v = [] {
+        const char* e = std::getenv("MOMA_K2_TARGET_WG");
+        const int n = e ? std::atoi(e) : 0;
+        return (n >= 8 && n <= 2048) ? n : 256;
+    }();
+    return v;
+}
+
 FlashPlan plan(int B, int K, int nterms = 1) {
     FlashPlan p;
     p.nbt = (B + QROWS_WG - 1) / QROWS_WG;
     p.Bpad = p.nbt * QROWS_WG;
     const int ntiles = (K + KT - 1) / KT;
-    int want = 256 / (p.nbt * nterms);         // ~1 workgroup per CU over all terms
+    int want = target_workgroups() / (p.nbt * nterms);         // ~1 workgroup per CU over all terms
     if (want < 8) want = 8;
     if (want > 1024) want = 1024;
     want = (want / 8) * 8;
@@ -2114,7 +2125,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     if (B <= SMALL_B_MAX && dq != nullptr && one_pass_dim(d)) {
         // ---- small batches: key-half split (infonce_small_kernel), two virtual chunks per workgroup, 64 padded rows
         const int ntiles = (K + KT - 1) / KT;
-        const int tpc = (ntiles + 255) / 256;                              // ~1 workgroup per CU
+        const int tpc = (ntiles + target_workgroups() - 1) / target_workgroups();   // ~1 workgroup per CU
         const int nwg = (ntiles + tpc - 1) / tpc;
         const int Bp = 64;
         const size_t rows = (size_t)nwg * Bp;                              // (half of plan(B, K).nchunk * 128: the workspace formula holds)

@@ -107,6 +107,20 @@ def _check_kd_term(a, opt, contrast, kd, rec, heads):
     assert torch.equal(contrast.memory[untouched], rec["queue"][untouched])
 
 
+def test_config1_effnet_b0_pair_full_size():
+    """BASELINE configs[1] ITSELF, the configuration the headline metric is quoted on and bench.py times: EfficientNet-B0 student +
+    teacher, 224 x 224, per-GPU batch 256, queue K = 65536 x d = 512 (--head mlp), 4-head attention-KD path, bf16 -- three steps of
+    the loop with the second step's K1 -> K2 -> K3 checked against the numpy oracle (round 4 carried this config by bench.py and by
+    G5c, the same KD shapes on a resnet8 backbone, only)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a, opt, contrast, kd, rec = _three_steps(["--no_cpu_baseline"])
+    assert (a.model, a.batch_size, a.image_size, a.nce_k, a.head, a.amp) == ("effiB0", 256, 224, 65536, "mlp", "bf16")
+    assert contrast.memory.shape == (65536, 512) and contrast.memory.dtype == torch.bfloat16 and kd.atts_q.num_heads == 4
+    assert opt.s_dim == 1280 and opt.t_dim == 1280
+    _check_kd_term(a, opt, contrast, kd, rec, heads=4)
+
+
 def test_config2_vit_small_pair_full_size():
     """BASELINE configs[2] as named: ViT-Small student + teacher, 224 x 224, per-GPU batch 256, 8-head attention-KD path
     (d = 384 -> head dim 48 on the K1 fast path, one-pass K2 at d = 384), bf16."""
