@@ -149,25 +149,29 @@ def _latest_profile(pattern):
 
 
 def k2_pmc_traffic():
-    """HBM bytes per launch of the one-pass kernel from the newest committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of scripts/bench_k2.py on the bench shape, summarised in profiles/rNN_k2_pmc.csv): FETCH_SIZE is
-    doubled per the guide's gfx950 correction.  None when no summary is present."""
+    """HBM bytes per launch of the one-pass kernel, and of the whole K2 call (one-pass kernel + combine; the queue pre-fetch sweep
+    of rounds 1-4 is off), from the newest committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
+    scripts/bench_k2.py on the bench shape, summarised in profiles/rNN_k2_pmc.csv): FETCH_SIZE is doubled per the guide's gfx950
+    correction.  -> (kernel bytes, source, whole-call bytes or None); None when no summary is present.  The whole-call figure
+    needs a summary collected in dq_only mode (round 5 on: the combine kernel's rows then count the step's kind of launch only)."""
     import csv
     f = _latest_profile("r*_k2_pmc.csv")
     if f is None:
         return None
-    fetch = write = None
+    c = {}
     for r in csv.DictReader(open(f)):
-        if r["kernel"].startswith("moma::infonce_flash_kernel<512, true>"):
-            if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["mean_per_launch"])
-            if r["counter"] == "WRITE_SIZE":
-                write = float(r["mean_per_launch"])
-    if fetch is None or write is None:
+        for key, name in (("flash", "moma::infonce_flash_kernel<512, true>"), ("combine", "moma::infonce_combine_kernel")):
+            if r["kernel"].startswith(name) and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                c[(key, r["counter"])] = (float(r["mean_per_launch"]), int(r["launches"]))
+    if ("flash", "FETCH_SIZE") not in c or ("flash", "WRITE_SIZE") not in c:
         return None
     import hashlib
     src = f"profiles/{os.path.basename(f)}#sha1:{hashlib.sha1(open(f, 'rb').read()).hexdigest()[:12]}"
-    return int((2 * fetch + write) * 1024), src
+    kb = lambda key: 2 * c[(key, "FETCH_SIZE")][0] + c[(key, "WRITE_SIZE")][0]
+    whole = None
+    if ("combine", "FETCH_SIZE") in c and ("combine", "WRITE_SIZE") in c and c[("combine", "FETCH_SIZE")][1] == c[("flash", "FETCH_SIZE")][1]:
+        whole = int((kb("flash") + kb("combine")) * 1024)
+    return int(kb("flash") * 1024), src, whole
 
 
 def pmc_fracs():
@@ -492,7 +496,10 @@ def main():
     # per-step times: GPU = between the HIP events recorded at the end of consecutive steps (stream time, includes queueing
     # behind the previous step); host = when the host finished issuing the step
     # (host issue is WALL time: once the host is a few steps ahead it blocks on the full launch queue and the figure tends to
-    #  the GPU's step time; host cpu = CPU time of the issuing thread, what the step costs the host when nothing blocks it)
+    #  the GPU's step time.  host cpu = CPU time of the issuing thread -- NOT a cost-when-unblocked figure either: the runtime
+    #  SPINS on a full queue, so thread time tracks the wall time there (driver line of round 4: 44.5 ms of "cpu" in a 39.8 ms
+    #  step).  What the step costs the host when nothing blocks it is host_issue_ms_min: the first timed steps, issued into an
+    #  empty queue -- 6.3-6.6 ms with graph packet capture off, hip_env.py.)
     step_gpu, step_host, step_cpu, prev_e, prev_t, prev_c = [], [], [], e_start, t0, c0
     for t_host, ev, t_cpu in opt.step_events:
         step_gpu.append(prev_e.elapsed_time(ev))
@@ -563,6 +570,11 @@ def main():
             tr = k2_pmc_traffic()                       # bytes per launch: PMC passes of the same kernel, committed summary
             if tr is not None:
                 roof["traffic"], roof["traffic_source"] = tr[0], tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/bench_k2.py; not measured in this run)"
+                # every kernel of the K2 call: the one-pass kernel + the combine that reads its split-K partials back (the side-stream
+                # sweep that pre-fetched the queue -- a second 67 MB read per step -- is off since round 5: opt.prefetch_queue)
+                roof["traffic_whole_call"] = tr[2]
+                roof["traffic_whole_call_note"] = ("one-pass kernel + combine, same PMC summary; queue pre-fetch sweep "
+                                                   + ("ON (its 67 MB per step are NOT in this figure)" if a.prefetch_queue else "off"))
         k1f, k1b, k4 = rec.mean_ms("moma_mha_fwd"), rec.mean_ms("moma_mha_bwd"), rec.mean_ms("moma_ema_multi")
         k1g = rec.mean_ms("moma_mha_fwd_group2")
         n_par = sum(p.numel() for p in model_s.parameters())
@@ -611,6 +623,8 @@ def main():
             "host_issue_ms_median": round(med(step_host), 3) if step_host else None,
             "host_issue_ms_min": round(min(step_host), 3) if step_host else None,
             "host_cpu_ms_median": round(med(step_cpu), 3) if step_cpu else None,
+            "host_note": "host_issue_ms_min = host cost of a step issued into an empty queue; the medians include blocking (wall) and "
+                         "the runtime's spin-wait (cpu) on a full launch queue once the host runs ahead of the GPU",
             "loss_mean_timed_steps": round(loss_avg, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",

@@ -2047,7 +2047,24 @@ int target_workgroups() {
     return v;
 }
 
-FlashPlan plan(int B, int K, int nterms = 1) {
+// Short queues (the reference's default --nce_k 16384, train_student_moma.py:103) and narrow rows (--feat_dim 128 / 256): a
+// workgroup's pass is a fixed ~10 us (dispatch, Q + first tile, partial stores) plus its tiles, and every chunk is one more partial
+// the combine reads back (combine: 5 / 7 / 10.5 / 18+ us at 32 / 64 / 128 / 256 chunks).  When a workgroup's tile loop would run
+// for less than ~4 us the pass is cut into HALF as many chunks instead (repeatedly, down to 32): measured, one-pass kernel + combine
+// (profiles/r05_k2_plan_sweep.txt): (B, d, K) = (64, 512, 16384) 21.8 -> 18.3 us, (256, 128, 16384) 17.9 -> 15.4, (256, 256, 16384)
+// 21.4 -> 20.0; (256, 512, 16384) and every K = 65536 shape keep one workgroup per CU (halving them costs 1 - 13 us).
+// tile_ns: duration of one 32-key tile of the loop at d = 512 (1.63 us one-pass kernel, 1.44 us small-batch kernel), linear in d.
+template <typename F>
+void coarsen_short_passes(int& want, int& tpc, int ntiles, int d, long tile_ns_512, long tile_ns_fixed, F&& round) {
+    if (d > 512) return;                                   // (wide rows: two passes with their own grouping; a tile is long anyway)
+    const long tile_ns = tile_ns_512 * d / 512 + tile_ns_fixed;
+    while (want > 32 && (long)tpc * tile_ns < 4000) {
+        want = round(want / 2);
+        tpc = (ntiles + want - 1) / want;
+    }
+}
+
+FlashPlan plan(int B, int K, int d, int nterms = 1) {
     FlashPlan p;
     p.nbt = (B + QROWS_WG - 1) / QROWS_WG;
     p.Bpad = p.nbt * QROWS_WG;
@@ -2057,10 +2074,24 @@ FlashPlan plan(int B, int K, int nterms = 1) {
     if (want > 1024) want = 1024;
     want = (want / 8) * 8;
     int tpc = (ntiles + want - 1) / want;
+    coarsen_short_passes(want, tpc, ntiles, d, 1630, 150, [](int w) { return w < 8 ? 8 : (w / 8) * 8; });
     if (tpc < 1) tpc = 1;
     p.tiles_per_chunk = tpc;
     p.nchunk = (ntiles + tpc - 1) / tpc;       // no empty chunk by construction
     return p;
+}
+
+// small batches (infonce_small_kernel): workgroups of 64 padded rows, two virtual chunks each
+struct SmallPlan {
+    int nwg, tiles_per_wg;
+};
+SmallPlan small_plan(int K, int d) {
+    const int ntiles = (K + KT - 1) / KT;
+    int want = target_workgroups();                            // ~1 workgroup per CU
+    int tpc = (ntiles + want - 1) / want;
+    coarsen_short_passes(want, tpc, ntiles, d, 1440, 100, [](int w) { return w < 1 ? 1 : w; });
+    if (tpc < 1) tpc = 1;
+    return SmallPlan{(ntiles + tpc - 1) / tpc, tpc};
 }
 
 }  // namespace
@@ -2077,8 +2108,12 @@ bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec) {
 }
 
 size_t infonce_flash_workspace_bytes(int B, int d, int K) {
-    const FlashPlan p = plan(B, K);
-    const size_t rows = (size_t)p.nchunk * p.Bpad;
+    const FlashPlan p = plan(B, K, d);
+    size_t rows = (size_t)p.nchunk * p.Bpad;
+    if (B <= SMALL_B_MAX && d <= 512) {                      // (the small-batch path lays out 64-row partials of its own plan)
+        const size_t rs = (size_t)small_plan(K, d).nwg * 64;     // its rows: 5 float arrays + the O partials (4 + O in the formula below)
+        if (rs + rs / 4 + 64 > rows) rows = rs + rs / 4 + 64;
+    }
     const int ds = d > 512 ? 512 : d;                        // widest slab
     const int nslab = (d + 511) / 512;                       // one partial buffer per column slab
     size_t bytes = (size_t)nslab * rows * ds * 2 + 4 * rows * sizeof(float) + (size_t)p.Bpad * d * 2 + 1024;
@@ -2114,7 +2149,7 @@ void set_lds_attrs() {
 
 size_t infonce_qpack_bytes(int B, int d) {
     if (B < 1 || !one_pass_dim(d)) return 0;
-    return (size_t)plan(B, 1).Bpad * d * 2;
+    return (size_t)plan(B, 1, d).Bpad * d * 2;
 }
 
 // q_packed (nullable, one-pass widths only): q * inv_T * log2(e) as bf16 in infonce_qpack_kernel's layout, written by the
@@ -2124,11 +2159,10 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                                 hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed, hipEvent_t ev_call_end) {
     if (B <= SMALL_B_MAX && dq != nullptr && one_pass_dim(d)) {
         // ---- small batches: key-half split (infonce_small_kernel), two virtual chunks per workgroup, 64 padded rows
-        const int ntiles = (K + KT - 1) / KT;
-        const int tpc = (ntiles + target_workgroups() - 1) / target_workgroups();   // ~1 workgroup per CU
-        const int nwg = (ntiles + tpc - 1) / tpc;
+        const SmallPlan sp = small_plan(K, d);
+        const int tpc = sp.tiles_per_wg, nwg = sp.nwg;
         const int Bp = 64;
-        const size_t rows = (size_t)nwg * Bp;                              // (half of plan(B, K).nchunk * 128: the workspace formula holds)
+        const size_t rows = (size_t)nwg * Bp;                              // (infonce_flash_workspace_bytes covers this layout)
         float* m_part = (float*)ws;
         float* l_part = m_part + rows;
         float* x_part = l_part + rows;
@@ -2155,7 +2189,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
                               d, inv_T, nwg, Bp, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
         return hipGetLastError();
     }
-    const FlashPlan p = plan(B, K);
+    const FlashPlan p = plan(B, K, d);
     if (p.nchunk > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     const int dsl = d > 512 ? 512 : d;
@@ -2285,19 +2319,19 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 }
 
 size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K) {
-    const FlashPlan p = plan(B, K, n_terms);
+    const FlashPlan p = plan(B, K, d, n_terms);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     return (size_t)n_terms * (rows * d * 2 + 3 * rows * sizeof(float)) + (size_t)n_terms * p.Bpad * d * 2 + 2048;
 }
 
 bool infonce_multi_supported(int n_terms, int B, int d, int K, int qdtype, int prec) {
     return n_terms >= 1 && n_terms <= MULTI_MAX_TERMS && prec == MOMA_PREC_BF16 && qdtype == MOMA_DT_BF16 && one_pass_dim(d) && B >= 1 &&
-           K >= 1 && plan(B, K, n_terms).nchunk <= COMBINE_MAX_CHUNKS;
+           K >= 1 && plan(B, K, d, n_terms).nchunk <= COMBINE_MAX_CHUNKS;
 }
 
 hipError_t launch_infonce_multi(const moma_infonce_term_t* terms, int n_terms, int B, int d, int K, float inv_T, void* ws,
                                 hipStream_t st) {
-    const FlashPlan p = plan(B, K, n_terms);
+    const FlashPlan p = plan(B, K, d, n_terms);
     const size_t rows = (size_t)p.nchunk * p.Bpad;
     MultiArgs a{};
     a.n = n_terms;

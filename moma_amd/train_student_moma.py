@@ -195,18 +195,33 @@ def build_training(opt, device):
         raise NotImplementedError(opt.distill)
     criterion_list = nn.ModuleList([criterion_cls, criterion_div, criterion_kd])
     module_list.append(model_t)
-    # --amp fp16: the fused SGD takes GradScaler's scale and found-inf flag as DEVICE tensors (the update is skipped inside the
-    # kernel), so `scaler.step()` reads nothing back -- the stock path syncs the host once per step (`found_inf.item()`), which
-    # cost BASELINE configs[4] its run-ahead (round 4: 119 ms of host time in a 120 ms step) and kept the step out of HIP graphs
-    fused = getattr(opt, "amp", None) == "fp16" and torch.device(device).type == "cuda"
-    optimizer = optim.SGD(trainable_list.parameters(), lr=opt.learning_rate, momentum=opt.momentum,
-                          weight_decay=opt.weight_decay, **({"fused": True} if fused else {}))
     module_list.to(device)
     criterion_list.to(device)
     if getattr(opt, "channels_last", False):
         model_s.to(memory_format=torch.channels_last)
         model_t.to(memory_format=torch.channels_last)
+    optimizer = make_optimizer(trainable_list.parameters(), opt, device)      # (after the moves: its state follows the parameters' layout)
     return model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer
+
+
+def make_optimizer(params, opt, device):
+    """SGD as the reference builds it (train_student_moma.py:389-392).  --amp fp16 on a GPU: torch's FUSED SGD, which takes
+    GradScaler's scale and found-inf flag as DEVICE tensors (an overflowed step is skipped inside the kernel), so `scaler.step()`
+    reads nothing back -- the stock path syncs the host once per step (`found_inf.item()`), which cost BASELINE configs[4] its
+    run-ahead (round 4: 119 ms of host time in a 120 ms step) and kept the step out of HIP graphs.
+    The fused kernel's momentum buffers are created HERE, as zeros: torch allocates them uninitialised on the optimizer's first
+    step and fills them inside the kernel -- which does nothing when that step overflows, as the first steps under a GradScaler
+    do by design (initial scale 2^16): the second step then runs on garbage momentum (seen: configs[4] at full size, NaN weights
+    after its second step).  With dampening 0, `buf = momentum * 0 + grad` IS the first-step rule `buf = grad`."""
+    params = list(params)
+    fused = getattr(opt, "amp", None) == "fp16" and torch.device(device).type == "cuda"
+    optimizer = optim.SGD(params, lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay,
+                          **({"fused": True} if fused else {}))
+    if fused and opt.momentum != 0:
+        for p in params:
+            if p.requires_grad:
+                optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return optimizer
 
 
 def _rank_state_path(folder, rank):

@@ -1,5 +1,7 @@
 """Micro-benchmark of K2 (InfoNCE over the queue) through the C ABI: HIP-event time per launch, algorithmic
-GB/s and TFLOP/s.  usage: python scripts/bench_k2.py [B] [d] [K] [queue_dtype] [prec] [iters]"""
+GB/s and TFLOP/s.  usage: python scripts/bench_k2.py [B] [d] [K] [queue_dtype] [prec] [iters] [dq_only]
+(dq_only: only the launches with the gradient -- the training step's call -- so that per-kernel counter means of the combine
+kernel, whose name does not tell the two kinds apart, are those of that call)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,13 +13,14 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 qdt = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 prec = sys.argv[5] if len(sys.argv) > 5 else "bf16"
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 50
+dq_only = len(sys.argv) > 7 and sys.argv[7] == "dq_only"
 torch.manual_seed(0)
 dev = "cuda"
 q = torch.nn.functional.normalize(torch.randn(B, d, device=dev))
 k = torch.nn.functional.normalize(q + 0.3 * torch.randn(B, d, device=dev))
 queue = torch.nn.functional.normalize(torch.randn(K, d, device=dev)).to(torch.bfloat16 if qdt == "bf16" else torch.float32)
 qbytes = queue.element_size()
-for grad in (True, False):
+for grad in ((True,) if dq_only else (True, False)):
     qq = q.clone().requires_grad_(grad)
     for _ in range(5):
         ops.infonce_fused(qq, k, queue, 0.15, prec)

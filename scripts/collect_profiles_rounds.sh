@@ -48,7 +48,7 @@ k2s)
   cd $R; python scripts/summarise_profiles.py ${TAG}_k2_b64 $O/k2s
   python scripts/summarise_pmc.py profiles/${TAG}_k2_b64_pmc.csv $O/k2s_sq $O/k2s_fetch $O/k2s_write $O/k2s_tcc; cd /tmp ;;
 k2)
-  K2="python3 $R/scripts/bench_k2.py 256 512 65536 bf16 bf16 8"
+  K2="python3 $R/scripts/bench_k2.py 256 512 65536 bf16 bf16 12 dq_only"     # (the step's call: flash kernel with dq + its combine)
   prof k2 --kernel-trace --stats -d $O/k2 --output-format csv -- python3 $R/scripts/bench_k2.py 256 512 65536 bf16 bf16 20
   pmc3 k2 $K2
   cd $R; python scripts/summarise_profiles.py ${TAG}_k2 $O/k2

@@ -39,8 +39,11 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
     trainer = ContrastTrainer(opt)
     trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
     if amp == "fp16":            # as train_student_moma.build_training / main_worker do for --amp fp16
+        from moma_amd.train_student_moma import make_optimizer
         opt._grad_scaler = torch.amp.GradScaler("cuda", init_scale=scale0)
-        optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4, fused=True)
+        opt.learning_rate, opt.momentum, opt.weight_decay = lr, 0.9, 1e-4
+        optimizer = make_optimizer(trainable.parameters(), opt, dev)
+        assert optimizer.defaults.get("fused") and getattr(optimizer, "_step_supports_amp_scaling", False)
     else:
         optimizer = torch.optim.SGD(trainable.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
     student0 = torch.cat([p.detach().reshape(-1) for p in ms.parameters()]).clone()
@@ -111,21 +114,24 @@ def test_step_graphs_equal_the_eager_loop(model, overlap, prec, queue_dtype, amp
     np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=20 * tol)
 
 
-@pytest.mark.parametrize("scale0", [2.0 ** 10, 2.0 ** 40])
+@pytest.mark.parametrize("scale0", [2.0 ** 10, 2.0 ** 22])
 def test_step_graphs_with_fp16_and_a_grad_scaler(scale0):
     """--amp fp16 (BASELINE configs[4]): fp16 autocast + GradScaler with the step served from HIP graphs -- the captured backward
     starts from loss * scale (the scaler's DEVICE tensor, read at replay time), `scaler.step()` hands scale and found-inf to the
     fused SGD as device tensors and `scaler.update()` adjusts the scale on the device: no host read-back anywhere, replays and
     eager steps interleave.  Against the same run issued launch by launch: per-step losses, pointer, final scale (exact: the
-    same sequence of finite / overflowed steps).  scale0 = 2^40 overflows fp16 gradients for the first steps: those updates are
+    same sequence of finite / overflowed steps).  scale0 = 2^22 overflows fp16 gradients for the first steps: those updates are
     skipped INSIDE the optimizer kernel and the scale backs off -- on both paths alike, also across the capture."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    a = _run(True, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0)
-    b = _run(False, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0)
+    # (fp16 autocast is not reproducible run to run on this backbone either -- eager against eager parts by 1e-4 after ONE update at
+    #  lr 0.02 and by 6 % three steps later, while the loss falls from 8 to 2.5 --, so like the EfficientNet case this one takes small
+    #  steps: what a wrong scale, a skipped or a doubled update would do to the weights is 1000x larger than the tolerance on `delta`)
+    a = _run(True, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0, lr=2e-4)
+    b = _run(False, "resnet8", True, "bf16", "bf16", "fp16", scale0=scale0, lr=2e-4)
     assert a["replays"] == 3 + 6 and b["replays"] == 0 and a["ngraphs"] == 1
     assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"]
-    assert a["scale"] == b["scale"] and (a["scale"] < scale0 if scale0 > 2.0 ** 30 else a["scale"] == scale0), (a["scale"], b["scale"])
+    assert a["scale"] == b["scale"] and (a["scale"] < scale0 if scale0 > 2.0 ** 20 else a["scale"] == scale0), (a["scale"], b["scale"])
     assert np.isfinite(a["loss"]).all() and np.isfinite(b["loss"]).all()
     np.testing.assert_allclose(a["loss"], b["loss"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=5e-3, atol=5e-3)
