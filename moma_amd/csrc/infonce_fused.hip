@@ -2038,14 +2038,15 @@ struct FlashPlan {
 
 // Workgroups a pass over the queue is cut into: one per compute unit.  MOMA_K2_TARGET_WG (read once) overrides it for plan sweeps
 // (scripts/sweep_k2_plan.sh); every caller of plan() -- workspace sizes included -- sees the same value for the process's life.
-int target_workgroups() {
+int target_override() {                                  // 0: none
     static const int v = [] {
         const char* e = std::getenv("MOMA_K2_TARGET_WG");
         const int n = e ? std::atoi(e) : 0;
-        return (n >= 8 && n <= 2048) ? n : 256;
+        return (n >= 8 && n <= 2048) ? n : 0;
     }();
     return v;
 }
+int target_workgroups() { return target_override() ? target_override() : 256; }
 
 // Short queues (the reference's default --nce_k 16384, train_student_moma.py:103) and narrow rows (--feat_dim 128 / 256): a
 // workgroup's pass is a fixed ~10 us (dispatch, Q + first tile, partial stores) plus its tiles, and every chunk is one more partial
@@ -2057,6 +2058,7 @@ int target_workgroups() {
 template <typename F>
 void coarsen_short_passes(int& want, int& tpc, int ntiles, int d, long tile_ns_512, long tile_ns_fixed, F&& round) {
     if (d > 512) return;                                   // (wide rows: two passes with their own grouping; a tile is long anyway)
+    if (target_override()) return;                         // (a sweep asks for exactly that many workgroups)
     const long tile_ns = tile_ns_512 * d / 512 + tile_ns_fixed;
     while (want > 32 && (long)tpc * tile_ns < 4000) {
         want = round(want / 2);

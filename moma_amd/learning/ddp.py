@@ -74,13 +74,13 @@ def _all_agree(values, device, group=None, what="replicas"):
 _control_groups = {}
 
 
-def control_group(group=None):
+def control_group(group=None, force_new=False):
     """Host-side agreement channel next to the data group: the group itself when it runs on gloo, else a gloo group over the same
     ranks (made once per data group; COLLECTIVE: every rank of `group` must call it at the same point -- the wrap's constructor
     and wrap_student do).  Carries a few int64 on CPU tensors: verdicts and fingerprints, never data."""
-    key = (id(group) if group is not None else None, id(dist.group.WORLD))      # (a re-initialised process group is another key)
+    key = (id(group) if group is not None else None, id(dist.group.WORLD), bool(force_new))   # (a re-initialised process group is another key)
     if key not in _control_groups:
-        if dist.get_backend(group) == "gloo":
+        if dist.get_backend(group) == "gloo" and not force_new:      # (force_new: tests walk the RCCL-side branch on a gloo job)
             _control_groups[key] = group if group is not None else dist.group.WORLD
         else:
             ranks = dist.get_process_group_ranks(group) if group is not None else None
@@ -163,7 +163,9 @@ class FlatDataParallel(nn.Module):
             _all_agree(_fingerprint(state), state[0].device, group, "student replicas")     # as DDP's constructor verifies
         _flat_broadcast(state, group)                                                        # replicas start from rank 0
         self.flat_buffer_broadcast = FlatBufferBroadcast(module, group)
-        self._ctl = control_group(group) if dist.get_world_size(group) > 1 else None     # (collective: all ranks construct the wrap)
+        # (collective: all ranks construct the wrap.  MOMA_DP_CONTROL=new: a gloo group of its own even on a gloo job -- the branch
+        #  an RCCL job takes --, for the CPU rehearsals)
+        self._ctl = control_group(group, os.environ.get("MOMA_DP_CONTROL") == "new") if dist.get_world_size(group) > 1 else None
         self.allreduce_launches = 0
 
     def forward(self, *args, **kwargs):

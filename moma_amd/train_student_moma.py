@@ -204,7 +204,7 @@ def build_training(opt, device):
     return model_s, model_t, module_list, criterion_list, trainable_list, contrast, optimizer
 
 
-def make_optimizer(params, opt, device):
+def make_optimizer(params, opt, device, fused=None):
     """SGD as the reference builds it (train_student_moma.py:389-392).  --amp fp16 on a GPU: torch's FUSED SGD, which takes
     GradScaler's scale and found-inf flag as DEVICE tensors (an overflowed step is skipped inside the kernel), so `scaler.step()`
     reads nothing back -- the stock path syncs the host once per step (`found_inf.item()`), which cost BASELINE configs[4] its
@@ -214,13 +214,25 @@ def make_optimizer(params, opt, device):
     do by design (initial scale 2^16): the second step then runs on garbage momentum (seen: configs[4] at full size, NaN weights
     after its second step).  With dampening 0, `buf = momentum * 0 + grad` IS the first-step rule `buf = grad`."""
     params = list(params)
-    fused = getattr(opt, "amp", None) == "fp16" and torch.device(device).type == "cuda"
+    if fused is None:                              # (an explicit value: the CPU test of this function)
+        fused = getattr(opt, "amp", None) == "fp16" and torch.device(device).type == "cuda"
     optimizer = optim.SGD(params, lr=opt.learning_rate, momentum=opt.momentum, weight_decay=opt.weight_decay,
                           **({"fused": True} if fused else {}))
     if fused and opt.momentum != 0:
         for p in params:
             if p.requires_grad:
                 optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+    if fused:
+        # torch._fused_sgd_ rewrites the parameters WITHOUT advancing their version counters (checked: `_version` stays put, the
+        # plain / foreach paths advance it) -- and everything here that keeps a derived copy of a weight keys it on that counter
+        # (the bf16 weight packs of the attention modules, ops.py).  Left alone the eager loop trains atts_q against the packs of
+        # its FIRST step (seen: the eager loop learning visibly slower than the graph-served one, which rebuilds the packs inside
+        # its graphs).  One host-side call per step, no kernel.
+        def _advance_versions(opt_, _args, _kwargs):
+            ps = [q for g in opt_.param_groups for q in g["params"] if q.grad is not None]
+            if ps:
+                torch.autograd.graph.increment_version(ps)
+        optimizer.register_step_post_hook(_advance_versions)
     return optimizer
 
 

@@ -352,6 +352,16 @@ def _safety_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def test_flat_wrap_safety_checks_over_a_separate_control_group(tmp_path, monkeypatch):
+    """The same checks with the host-side agreement channel as a gloo group OF ITS OWN next to the data group (what a job on RCCL
+    gets: `dist.new_group(backend="gloo")` beside the nccl communicator), forced here on a gloo job by MOMA_DP_CONTROL=new."""
+    monkeypatch.setenv("MOMA_DP_CONTROL", "new")
+    out = str(tmp_path / "safe2")
+    mp.spawn(_safety_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")):
+        assert r["gradset_refused"] and r["late_change_refused"] and r["n_coll"] == 1 and r["avg_ok"]
+
+
 def test_flat_wrap_safety_checks(tmp_path):
     """ADVICE r3 (learning/ddp.py): what stock DDP verifies and the flat wrap has to verify itself -- identical replica layouts at
     construction, identical gradient sets before the flat all-reduce (a mismatch raises on EVERY rank instead of hanging or

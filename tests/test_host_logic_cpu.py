@@ -204,3 +204,32 @@ def test_visible_gpu_count_reads_sysfs_and_the_visibility_masks(monkeypatch, tmp
     assert bench.visible_gpu_count() == 2
     monkeypatch.setattr(glob, "glob", lambda pat: [])
     assert bench.visible_gpu_count() is None
+
+
+def test_fused_sgd_keeps_weight_versions_moving_and_starts_from_zero_momentum():
+    """train_student_moma.make_optimizer, --amp fp16 path (torch's fused SGD; forced onto the CPU here): (1) a step advances the
+    parameters' version counters -- torch._fused_sgd_ itself does not, and the attention weight packs are keyed on them; (2) the
+    momentum buffers exist before the first step, as zeros, so a first step that the GradScaler skips (found_inf) cannot leave
+    them uninitialised; with dampening 0 the first real step equals the plain optimizer's."""
+    import moma_amd.train_student_moma as tsm
+    torch.manual_seed(0)
+    w0 = torch.randn(5, 3)
+    g = [torch.randn(5, 3), torch.randn(5, 3)]
+    opt = argparse.Namespace(amp="fp16", learning_rate=0.1, momentum=0.9, weight_decay=1e-2)
+    a = nn.Parameter(w0.clone())
+    fused = tsm.make_optimizer([a], opt, "cpu", fused=True)
+    assert fused.defaults.get("fused") and torch.equal(fused.state[a]["momentum_buffer"], torch.zeros(5, 3))
+    b = nn.Parameter(w0.clone())
+    plain = torch.optim.SGD([b], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    # a skipped first step (found_inf = 1): nothing moves, the buffer stays zero -- not garbage
+    a.grad = g[0].clone()
+    fused.grad_scale, fused.found_inf = torch.tensor(1.0), torch.tensor(1.0)
+    fused.step()
+    del fused.grad_scale, fused.found_inf
+    assert torch.equal(a.detach(), w0) and torch.equal(fused.state[a]["momentum_buffer"], torch.zeros(5, 3))
+    v0 = a._version
+    for gi in g:
+        a.grad, b.grad = gi.clone(), gi.clone()
+        fused.step(); plain.step()
+        assert torch.allclose(a.detach(), b.detach(), rtol=0, atol=1e-6)
+    assert a._version >= v0 + 2
