@@ -2088,10 +2088,17 @@ struct SmallPlan {
     int nwg, tiles_per_wg;
 };
 SmallPlan small_plan(int K, int d) {
+    // one workgroup per CU; short queues (fewer than 8 tiles per workgroup: K < 65536) take half as many -- measured
+    // (profiles/r05_k2_plan_sweep.txt, kernel + combine): K = 16384: d = 128 / 256 / 512 16.3 / 18.9 / 21.8 us at 256 workgroups,
+    // 13.3 / 14.6 / 18.3 at 128, 13.8 / 15.1 / 20.7 at 64; K = 65536: 19.7 / 21.8 / 29.4 at 256, 19.7 / 22.9 / 32.2 at 128
+    (void)d;
     const int ntiles = (K + KT - 1) / KT;
-    int want = target_workgroups();                            // ~1 workgroup per CU
+    int want = target_workgroups();
     int tpc = (ntiles + want - 1) / want;
-    coarsen_short_passes(want, tpc, ntiles, d, 1440, 100, [](int w) { return w < 1 ? 1 : w; });
+    if (!target_override() && tpc < 8 && want > 128) {
+        want = 128;
+        tpc = (ntiles + want - 1) / want;
+    }
     if (tpc < 1) tpc = 1;
     return SmallPlan{(ntiles + tpc - 1) / tpc, tpc};
 }

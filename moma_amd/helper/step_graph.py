@@ -73,7 +73,7 @@ class PermFeed:
             self.done[j].synchronize()                   # (four steps back: long done)
         torch.randperm(self.n, out=self.pinned[j])
         self.static.copy_(self.pinned[j], non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)      # (a host that has run four steps ahead SLEEPS in synchronize() instead of spinning)
         ev.record()
         self.done[j] = ev
 

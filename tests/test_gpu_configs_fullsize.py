@@ -167,6 +167,8 @@ def _losses(argv, steps_per_epoch):
     torch.manual_seed(12345)
     model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
     trainer = ContrastTrainer(opt)
+    if opt.amp == "fp16":
+        opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     for ep, n in enumerate(steps_per_epoch):
         loader = SyntheticLoader(n, a.batch_size, a.image_size, a.n_cls, 12345 + ep, dev)
         train_distill_moma(ep, loader, module_list, criterion_list, trainer, contrast, optimizer, opt)
@@ -194,4 +196,22 @@ def test_config2_step_graphs_survive_eager_work_between_replays():
     assert replays == 2 + 6 and none == 0                     # (the ViT has no BatchNorm: one variant, captured at the 4th step)
     assert finite_g and finite_e and np.isfinite(lg).all() and np.isfinite(kg).all()
     np.testing.assert_allclose(lg, le, rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(kg, ke, rtol=5e-3, atol=5e-3)
+
+
+def test_config4_fp16_grad_scaler_step_graphs_against_the_eager_loop():
+    """BASELINE configs[4] (single-GPU form) at full size with the step SERVED FROM HIP GRAPHS (round 5: fp16 + GradScaler joined
+    the graphable configurations -- fused SGD, scale and found-inf flag stay on the device): two epochs, a print after every step,
+    against the same run issued launch by launch.  The scaler starts at 2^16: the first steps overflow and are skipped inside the
+    optimizer kernel on both paths; small learning rate so that the two trajectories stay comparable (fp16 autocast is not
+    reproducible run to run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    argv = ["--model", "ResNet50", "--model_t", "vit_base_patch16_224", "--image_size", "512", "--batch_size", "64", "--amp", "fp16",
+            "--learning_rate", "2e-4", "--no_cpu_baseline"]
+    lg, kg, replays, finite_g = _losses(argv, [5, 6])
+    le, ke, none, finite_e = _losses(argv + ["--no_graph_student"], [5, 6])
+    assert replays >= 6 and none == 0, (replays, none)
+    assert finite_g and finite_e and np.isfinite(lg).all() and np.isfinite(le).all(), (lg, le)
+    np.testing.assert_allclose(lg, le, rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(kg, ke, rtol=5e-3, atol=5e-3)
