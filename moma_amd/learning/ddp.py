@@ -165,7 +165,13 @@ class FlatDataParallel(nn.Module):
         self.flat_buffer_broadcast = FlatBufferBroadcast(module, group)
         # (collective: all ranks construct the wrap.  MOMA_DP_CONTROL=new: a gloo group of its own even on a gloo job -- the branch
         #  an RCCL job takes --, for the CPU rehearsals)
-        self._ctl = control_group(group, os.environ.get("MOMA_DP_CONTROL") == "new") if dist.get_world_size(group) > 1 else None
+        self._ctl = None
+        if dist.get_world_size(group) > 1:
+            try:
+                self._ctl = control_group(group, os.environ.get("MOMA_DP_CONTROL") == "new")
+            except Exception as e:                               # (no usable gloo transport: the per-step agreement is skipped, loudly)
+                print(f"[moma] data-parallel control group unavailable ({type(e).__name__}: {e}): gradient sets are not "
+                      f"re-verified per step")
         self.allreduce_launches = 0
 
     def forward(self, *args, **kwargs):
@@ -212,7 +218,12 @@ def wrap_student(model: nn.Module, device_ids=None, group=None, mode: str | None
     mode = mode or os.environ.get("MOMA_DP", "auto")
     if mode == "auto":
         dev = next(model.parameters()).device
-        ctl = control_group(group) if dist.get_world_size(group) > 1 else None
+        ctl = None
+        if dist.get_world_size(group) > 1:
+            try:
+                ctl = control_group(group)
+            except Exception as e:
+                print(f"[moma] data-parallel control group unavailable ({type(e).__name__}: {e})")
         try:
             ok = collective_self_test(dev, group)
         except Exception as e:                                   # a backend that cannot run one of the two collectives

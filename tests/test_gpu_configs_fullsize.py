@@ -143,7 +143,7 @@ def test_config4_vit_base_to_resnet50_full_size_single_gpu_form():
     _check_kd_term(a, opt, contrast, kd, rec, heads=4)
 
 
-def _losses(argv, steps_per_epoch):
+def _losses(argv, steps_per_epoch, scaler_init=None):
     """per-step (loss, loss_kd) of bench.py's loop over several epochs, printing EVERY step (eager kernels + a read-back between
     the replays of the step graphs)"""
     if ROOT not in sys.path:
@@ -168,7 +168,7 @@ def _losses(argv, steps_per_epoch):
     model_s, model_t, module_list, criterion_list, _tr, contrast, optimizer = build_training(opt, dev)
     trainer = ContrastTrainer(opt)
     if opt.amp == "fp16":
-        opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
+        opt._grad_scaler = torch.amp.GradScaler("cuda", **({} if scaler_init is None else {"init_scale": scaler_init}))
     for ep, n in enumerate(steps_per_epoch):
         loader = SyntheticLoader(n, a.batch_size, a.image_size, a.n_cls, 12345 + ep, dev)
         train_distill_moma(ep, loader, module_list, criterion_list, trainer, contrast, optimizer, opt)
@@ -202,15 +202,18 @@ def test_config2_step_graphs_survive_eager_work_between_replays():
 def test_config4_fp16_grad_scaler_step_graphs_against_the_eager_loop():
     """BASELINE configs[4] (single-GPU form) at full size with the step SERVED FROM HIP GRAPHS (round 5: fp16 + GradScaler joined
     the graphable configurations -- fused SGD, scale and found-inf flag stay on the device): two epochs, a print after every step,
-    against the same run issued launch by launch.  The scaler starts at 2^16: the first steps overflow and are skipped inside the
-    optimizer kernel on both paths; small learning rate so that the two trajectories stay comparable (fp16 autocast is not
-    reproducible run to run)."""
+    against the same run issued launch by launch.  Small learning rate so that the two trajectories stay comparable (fp16 autocast
+    is not reproducible run to run), and the scaler starts at 2^12: at the default 2^16 the first step overflows, the scale settles
+    at 2^15 -- and there the largest element of conv1's fp16 weight gradient sits at 0.92 - 0.99 of the fp16 maximum, so every few
+    steps ONE element overflows and that step is skipped, on either path, in a different step from run to run
+    (scripts/diag_cfg4_graph.py: graph-served and eager runs alike).  That is the GradScaler doing its job, and tests/
+    test_gpu_step_graph.py covers skipped steps under graphs at a small size; here it would only make the comparison a lottery."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     argv = ["--model", "ResNet50", "--model_t", "vit_base_patch16_224", "--image_size", "512", "--batch_size", "64", "--amp", "fp16",
             "--learning_rate", "2e-4", "--no_cpu_baseline"]
-    lg, kg, replays, finite_g = _losses(argv, [5, 6])
-    le, ke, none, finite_e = _losses(argv + ["--no_graph_student"], [5, 6])
+    lg, kg, replays, finite_g = _losses(argv, [5, 6], scaler_init=4096.0)
+    le, ke, none, finite_e = _losses(argv + ["--no_graph_student"], [5, 6], scaler_init=4096.0)
     assert replays >= 6 and none == 0, (replays, none)
     assert finite_g and finite_e and np.isfinite(lg).all() and np.isfinite(le).all(), (lg, le)
     np.testing.assert_allclose(lg, le, rtol=2e-2, atol=2e-2)

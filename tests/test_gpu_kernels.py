@@ -139,6 +139,9 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
                                        # bf16 queue + bf16 MFMA -> the one-pass flash kernel (ragged B, K tails)
                                        (100, 384, 5000, "bf16"), (300, 256, 777, "bf16"), (7, 512, 33, "bf16"),
                                        (129, 512, 65536, "bf16"), (200, 128, 16384, "bf16"), (9, 128, 65, "bf16"),
+                                       # the reference's own run-script shape (scripts/run_moma.sh: --batch_size 64 --feat_dim 512,
+                                       # --nce_k default 16384) and its neighbours: the plans round 5 cuts into fewer workgroups
+                                       (64, 512, 16384, "bf16"), (64, 128, 16384, "bf16"), (256, 256, 16384, "bf16"), (60, 256, 32768, "bf16"),
                                        # d > 512: column slabs over a score scratch (512 + 512 + 256, 512 + 128, 4 x 512, 512 + 384)
                                        (64, 1280, 4096, "bf16"), (33, 640, 1000, "bf16"), (40, 2048, 777, "bf16"),
                                        (130, 896, 2100, "bf16"),
