@@ -38,6 +38,7 @@
 
 // Tuning constants of the kernels below (each fixed by measurement on MI355X; DESIGN.md section 4 records the sweeps):
 #define MOMA_K2_WPV_SD 3        // wide P.K pass: key tiles (and their P) requested ahead; ring of SD + 1 slots of 16 KiB
+#define MOMA_K2_SMALL_AUX 0     // small-batch kernel (every key tile is read by ONE workgroup): cache policy of its queue stream
 
 namespace moma {
 namespace {
@@ -76,7 +77,8 @@ __device__ __forceinline__ DmaLane dma_lane_terms(int lane, int wave, unsigned p
     t.term = (unsigned)(rl * pitch + ((sl ^ swz(4 * wave + rl)) << 4));
     return t;
 }
-template <int D, bool PARTIAL = true>
+// AUX: cache policy bits of the load (0 = default, 2 = nt: the line is streamed, not kept)
+template <int D, bool PARTIAL = true, int AUX = 0>
 __device__ __forceinline__ void dma_piece(int i, const DmaLane& dl, const bf16_raw* __restrict__ queue, long key0, int K,
                                           char* buf, int wave, int lane) {
     const int pc = i * 4 + wave;                // wave-uniform
@@ -92,14 +94,14 @@ __device__ __forceinline__ void dma_piece(int i, const DmaLane& dl, const bf16_r
     }
     char* dst = buf + seg * 8192 + rg * 1024;   // wave-uniform LDS base; lane L lands at +16*L
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tile + off),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
 }
 
-template <int D>
+template <int D, int AUX = 0>
 __device__ __forceinline__ void dma_tile(const DmaLane& dl, const bf16_raw* __restrict__ queue, long key0, int K,
                                          char* buf, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < D / 64; ++i) dma_piece<D>(i, dl, queue, key0, K, buf, wave, lane);
+    for (int i = 0; i < D / 64; ++i) dma_piece<D, true, AUX>(i, dl, queue, key0, K, buf, wave, lane);
 }
 
 // Q operand pre-pack: scale by log2(e)/T, round to bf16 and store in MFMA-fragment order so that every
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
         asm volatile("" : "+s"(tb));
 #pragma unroll
         for (int j = 0; j < NBUF - 1; ++j)
-            if (j < npro) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+            if (j < npro) dma_tile<D, MOMA_K2_SMALL_AUX>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
     };
     issue_ring();
 
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
                 __builtin_amdgcn_sched_barrier(0);
                 if (s + RD < KS2) rd(s + RD);
                 if constexpr (REFILL != 0) {
-                    if ((s & 1) == 1) dma_piece<D, REFILL == 2>(s >> 1, dl, queue, rkey0, K, rbuf, wave, lane);
+                    if ((s & 1) == 1) dma_piece<D, REFILL == 2, MOMA_K2_SMALL_AUX>(s >> 1, dl, queue, rkey0, K, rbuf, wave, lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

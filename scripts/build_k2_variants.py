@@ -80,6 +80,8 @@ VARIANTS["occ1pad"] = [LDSPAD]
 VARIANTS["diet_occ2"] = DIET + [OCC2, GRID512]
 VARIANTS["diet_occ1"] = DIET + [LDSPAD]
 VARIANTS["diet_occ1_grid512"] = DIET + [GRID512, LDSPAD]
+# round 5: non-temporal queue stream of the small-batch kernel (each tile is read by exactly one workgroup)
+VARIANTS["small_nt"] = [("#define MOMA_K2_SMALL_AUX 0 ", "#define MOMA_K2_SMALL_AUX 2 ")]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()
