@@ -495,11 +495,11 @@ def main():
     kev.enabled = False
     # per-step times: GPU = between the HIP events recorded at the end of consecutive steps (stream time, includes queueing
     # behind the previous step); host = when the host finished issuing the step
-    # (host issue is WALL time: once the host is a few steps ahead it blocks on the full launch queue and the figure tends to
-    #  the GPU's step time.  host cpu = CPU time of the issuing thread -- NOT a cost-when-unblocked figure either: the runtime
-    #  SPINS on a full queue, so thread time tracks the wall time there (driver line of round 4: 44.5 ms of "cpu" in a 39.8 ms
-    #  step).  What the step costs the host when nothing blocks it is host_issue_ms_min: the first timed steps, issued into an
-    #  empty queue -- 6.3-6.6 ms with graph packet capture off, hip_env.py.)
+    # (host issue is WALL time: the graph-served loop paces itself two steps ahead of the GPU (helper/step_graph.py:_throttle), so
+    #  its median tends to the GPU's step time.  host cpu = CPU time of the issuing thread: with the pacing -- a poll of the step's
+    #  event between short sleeps -- it is what a step costs the host, ~7 ms.  Every wait INSIDE this runtime spins, blocking-sync
+    #  events included (scripts/diag_blocking_event.py): without the pacing the thread burned wall = CPU time in hipGraphLaunch,
+    #  44.5 ms per 39.8 ms step in round 4's driver line.  host_issue_ms_min = a step issued into an empty queue.)
     step_gpu, step_host, step_cpu, prev_e, prev_t, prev_c = [], [], [], e_start, t0, c0
     for t_host, ev, t_cpu in opt.step_events:
         step_gpu.append(prev_e.elapsed_time(ev))
@@ -623,8 +623,9 @@ def main():
             "host_issue_ms_median": round(med(step_host), 3) if step_host else None,
             "host_issue_ms_min": round(min(step_host), 3) if step_host else None,
             "host_cpu_ms_median": round(med(step_cpu), 3) if step_cpu else None,
-            "host_note": "host_issue_ms_min = host cost of a step issued into an empty queue; the medians include blocking (wall) and "
-                         "the runtime's spin-wait (cpu) on a full launch queue once the host runs ahead of the GPU",
+            "host_note": "host_cpu_ms_median = CPU time of the issuing thread per step (the graph-served loop sleeps between polls of "
+                         "the step-before-last's event instead of spinning inside the runtime); host_issue_ms_median = wall time, "
+                         "paced by the GPU; host_issue_ms_min = a step issued into an empty queue",
             "loss_mean_timed_steps": round(loss_avg, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.moma_prec == "bf16" else "f32", "data": "synthetic",

@@ -40,6 +40,7 @@ from __future__ import annotations
 
 import gc
 import os
+import time
 
 import torch
 
@@ -162,14 +163,20 @@ class StepGraphs:
         return self._replay(cap, images, labels)
 
     def _throttle(self):
-        """The host issues a replayed step in ~6 ms against tens of ms of GPU time; left alone it runs ahead until the stream's
-        hardware queue is full and then SPINS inside the runtime for a free slot -- a full core per rank for nothing (round 4's
-        driver line: 44.5 ms of CPU time in a 39.8 ms step).  Instead it waits -- SLEEPING: a blocking-sync event -- until the step
-        before the last one has finished: two steps stay queued (the one executing and the next), the GPU never runs dry."""
+        """The host issues a replayed step in ~6 ms against tens of ms of GPU time.  Left alone it runs ahead until the runtime
+        has no room for another launch (kernel-argument pool, hardware queue) and waits INSIDE hipGraphLaunch -- and on this
+        platform every host-side wait of the runtime is a spin: hipEventSynchronize with a blocking-sync event, hipStreamSynchronize
+        and the launch path all burn wall time = CPU time (scripts/diag_blocking_event.py; ROC_ACTIVE_WAIT_TIMEOUT=0 changes nothing)
+        -- a full core per rank, eight of them on a node (round 4's driver line: 44.5 ms of CPU time in a 39.8 ms step).
+        So the loop paces itself: before issuing step k it waits until step k-2 has finished by POLLING its event between short
+        sleeps.  Two steps stay queued (the one executing and the next): the GPU never runs dry, the launches find room, and the
+        host's CPU time per step is what issuing costs."""
         evs = self.__dict__.setdefault("_step_done", [])
         if len(evs) >= 2:
-            evs.pop(0).synchronize()
-        ev = torch.cuda.Event(blocking=True)
+            ev = evs.pop(0)
+            while not ev.query():
+                time.sleep(0.0005)
+        ev = torch.cuda.Event()
         ev.record()                                        # (behind everything the loop issued for the previous step, optimizer included)
         evs.append(ev)
 
