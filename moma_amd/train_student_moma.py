@@ -335,6 +335,8 @@ def main_worker(gpu, ngpus_per_node, opt):
         model_t.load_state_dict(ck["model_t"])
         criterion_list[2].load_state_dict(ck["criterion_kd"])
         optimizer.load_state_dict(ck["optimizer"])
+        if getattr(opt, "_grad_scaler", None) is not None and ck.get("grad_scaler"):
+            opt._grad_scaler.load_state_dict(ck["grad_scaler"])         # (--amp fp16: the loss scale continues where it was)
         # per-rank state (the queue and its pointer are per rank in the default per_rank mode, and so are the RNG streams)
         # sits next to the shared file; a run resumed on fewer / other ranks falls back to rank 0's queue
         rs = _load_rank_state(os.path.dirname(opt.resume), opt.rank, ck["epoch"], device)
@@ -392,7 +394,8 @@ def main_worker(gpu, ngpus_per_node, opt):
             _atomic_save({"epoch": epoch, "model": model_s.state_dict(), "model_t": model_t.state_dict(),
                           "criterion_kd": criterion_list[2].state_dict(),
                           "contrast": contrast.state_dict() if contrast is not None else None,
-                          "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1},
+                          "optimizer": optimizer.state_dict(), "best_acc": best_acc, "best_f1": best_f1,
+                          "grad_scaler": opt._grad_scaler.state_dict() if getattr(opt, "_grad_scaler", None) is not None else None},
                          os.path.join(opt.save_folder, "ckpt_last.pth"))
         # ... and the per-rank part (queue + pointer of THIS rank, RNG streams) by every rank; both carry the epoch and a
         # resume only pairs files of the same epoch (_load_rank_state)

@@ -34,13 +34,17 @@ def test_cli_trains_on_synthetic(tmp_path, extra):
     assert params and json.load(open(params[0]))["nce_t"] == 0.15       # forced for --distill moma (reference :135)
 
 
-def test_cli_resume_continues_queue_pointer(tmp_path):
-    """the trainer's own checkpoint carries queue + pointer + CMO + EMA teacher; --resume continues."""
+@pytest.mark.parametrize("amp", [None, "fp16"])
+def test_cli_resume_continues_queue_pointer(tmp_path, amp):
+    """the trainer's own checkpoint carries queue + pointer + CMO + EMA teacher; --resume continues.
+    amp = fp16: the fused SGD's state (momentum buffers created up front) and the GradScaler's scale travel too."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     base = [sys.executable, os.path.join(ROOT, "train_student_moma.py"), "--distill", "moma", "--model_s", "resnet8x4",
             "--model_t", "resnet8x4", "--dataset", "cifar100", "--n_cls", "2", "--batch_size", "32", "--steps_per_epoch", "5",
             "--nce_k", "1024", "--head", "mlp", "--feat_dim", "128", "-c", "1", "-d", "1", "-b", "1", "--miopen_find", "off", "--save_root", str(tmp_path)]
+    if amp:
+        base += ["--amp", amp]
     r = subprocess.run(base + ["--epochs", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt_last.pth"]
@@ -57,6 +61,14 @@ def test_cli_resume_continues_queue_pointer(tmp_path):
     rs = torch.load(mine, map_location="cpu", weights_only=False)
     assert "per-rank state found" in r.stdout
     assert rs["contrast"]["_extra_state"]["index"] == (10 * 32) % 1024 and set(rs["rng"]) == {"python", "numpy", "torch", "cuda"}
+    if amp == "fp16":
+        # the scale after epoch 1 is what epoch 2 starts from (a fresh scaler would start at 2^16 again and could only be <= it)
+        assert state["grad_scaler"]["scale"] <= 65536.0 and state2["grad_scaler"]["scale"] <= state["grad_scaler"]["scale"]
+        assert state2["grad_scaler"]["_growth_tracker"] >= state["grad_scaler"]["_growth_tracker"] or \
+            state2["grad_scaler"]["scale"] < state["grad_scaler"]["scale"]
+        assert all(v["momentum_buffer"] is not None for v in state2["optimizer"]["state"].values())
+    else:
+        assert state.get("grad_scaler") is None
 
 
 def test_cli_distill_kd_default_path(tmp_path):
