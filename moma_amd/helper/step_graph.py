@@ -194,18 +194,24 @@ class StepGraphs:
         side = st.side_stream()
         if side is not None:
             side.wait_stream(main)                         # last step's optimizer, this step's inputs
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), ops.trace_range("moma_step/g_teacher"):
                 cap.g_teacher.replay()
-            cap.g_student.replay()
+            with ops.trace_range("moma_step/g_student"):
+                cap.g_student.replay()
             main.wait_stream(side)
             st.prefetch_queue()                            # (only with opt.prefetch_queue: on the side stream, under g_query)
         else:
-            cap.g_student.replay()
-            cap.g_teacher.replay()
-        cap.g_query.replay()
+            with ops.trace_range("moma_step/g_student"):
+                cap.g_student.replay()
+            with ops.trace_range("moma_step/g_teacher"):
+                cap.g_teacher.replay()
+        with ops.trace_range("moma_step/g_query"):
+            cap.g_query.replay()
         fw = cap.fw
-        st.contrast.forward_fused_into(fw["f_s"], fw["k"], fw["all_k"], None if cap.qpack is None else cap.qpack.buf, cap.k2)
-        cap.g_bwd.replay()
+        with ops.trace_range("moma_step/K2_K3"):
+            st.contrast.forward_fused_into(fw["f_s"], fw["k"], fw["all_k"], None if cap.qpack is None else cap.qpack.buf, cap.k2)
+        with ops.trace_range("moma_step/g_bwd"):
+            cap.g_bwd.replay()
         for m, dn in cap.bn_delta:
             m._nbt_pending += dn
         for p, g in cap.grads:

@@ -86,11 +86,39 @@ class _NullCtx:
         return False
 
 
+# Optional tracing (MOMA_ROCTX=1): a roctx range (torch.cuda.nvtx = roctx on ROCm) around every C-ABI call of K1 - K4 and around the
+# phases of the graph-served step (helper/step_graph.py), for `rocprofv3 --marker-trace --kernel-trace -- python ...`.  The
+# reference has no tracing of its own; off by default: a range is two more host calls per library call.
+_ROCTX = __import__("os").environ.get("MOMA_ROCTX", "0") == "1"
+
+
+class _Range:
+    def __init__(self, name, inner=None):
+        self.name, self.inner = name, inner
+
+    def __enter__(self):
+        torch.cuda.nvtx.range_push(self.name)
+        if self.inner is not None:
+            self.inner.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.inner is not None:
+            self.inner.__exit__(*a)
+        torch.cuda.nvtx.range_pop()
+        return False
+
+
+def trace_range(name):
+    """context manager: a roctx range when MOMA_ROCTX=1, nothing otherwise"""
+    return _Range(name) if _ROCTX else _NullCtx()
+
+
 def _timed(name):
     # (no events inside a stream capture: an event recorded there becomes a graph node and carries no timestamp)
     if _EVENT_RECORDER is None or torch.cuda.is_current_stream_capturing():
-        return _NullCtx()
-    return _EVENT_RECORDER(name)
+        return _Range(name) if _ROCTX else _NullCtx()
+    return _Range(name, _EVENT_RECORDER(name)) if _ROCTX else _EVENT_RECORDER(name)
 
 
 _DEBUG = __import__("os").environ.get("MOMA_DEBUG", "0") == "1"
@@ -160,8 +188,9 @@ def enqueue_(queue: torch.Tensor, rows: torch.Tensor, index: int) -> None:
     K, d = queue.shape
     if rows.dim() != 2 or rows.shape[1] != d:
         raise ValueError(f"rows must be [n,{d}], got {tuple(rows.shape)}")
-    check(lib.moma_enqueue(_ptr(queue), _ptr(rows), rows.shape[0], int(index), K, d, _qdtype(queue), _stream()),
-          "moma_enqueue")
+    with trace_range("moma_enqueue"):
+        check(lib.moma_enqueue(_ptr(queue), _ptr(rows), rows.shape[0], int(index), K, d, _qdtype(queue), _stream()),
+              "moma_enqueue")
 
 
 def queue_prefetch(queue: torch.Tensor, stream=None) -> None:
@@ -179,8 +208,9 @@ def enqueue_mirror_(queue: torch.Tensor, mirror: torch.Tensor, rows: torch.Tenso
     K, d = queue.shape
     if mirror.shape != queue.shape or rows.dim() != 2 or rows.shape[1] != d:
         raise ValueError(f"rows must be [n,{d}] and mirror {tuple(queue.shape)}, got {tuple(rows.shape)} / {tuple(mirror.shape)}")
-    check(lib.moma_enqueue_mirror(_ptr(queue), _ptr(mirror), _ptr(rows), rows.shape[0], int(index), K, d, _stream()),
-          "moma_enqueue_mirror")
+    with trace_range("moma_enqueue_mirror"):
+        check(lib.moma_enqueue_mirror(_ptr(queue), _ptr(mirror), _ptr(rows), rows.shape[0], int(index), K, d, _stream()),
+              "moma_enqueue_mirror")
 
 
 # ------------------------------------------------------------------------------------------------
