@@ -593,6 +593,11 @@ def main():
                                      "note": "launch / latency bound at N = batch (0.67 GFLOP per module call); HIP events around the C-ABI "
                                              "call (3 launches each; atts_k + atts_queue run as ONE group of 3 launches on the side stream); "
                                              "in-kernel matrix-pipe shares are in pmc.k1_*"}
+        if roof["bound"] == "mfma" and a.moma_prec == "bf16" and d <= 512:
+            # context, not the contract's figure: the peak above is the 2.4 GHz one; inside this kernel's loop the chip holds
+            # 1.80 GHz (s_memtime / s_memrealtime stamps of the diagnostic build, profiles/r04_flash_kernel_timeline.txt)
+            roof["sustained_clock_ghz_in_kernel"] = 1.80
+            roof["frac_of_peak_at_sustained_clock"] = round(roof["frac"] * 2.4 / 1.80, 4)
         roof["other"] = other
         kname = ("infonce_f32_flash_kernel (K2 one pass over the fp32 queue on the f32-input MFMA; moma_infonce_fused)"
                  if (a.moma_prec == "fp32" and a.queue_dtype == "fp32" and d in (128, 256, 384, 512, 768, 1024, 1280)) else
