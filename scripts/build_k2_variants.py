@@ -23,6 +23,11 @@ VARIANTS = {
     "nosoftmax": [('                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_a(c - SM_SHIFT);\n', ""),
                   ('                   if (c >= SM_SHIFT && c - SM_SHIFT < 16) sm_step_b(c - SM_SHIFT);\n', "")],
 }
+# CAUTION (round 5): variants that drop lgkmcnt waits are not just numerically garbage.  The LDS reads are inline asm whose destination
+# registers the compiler considers free again after their last use; without the wait a late LDS return can land in a register that
+# has since been re-used -- e.g. as the address of the next LDS-DMA piece.  A burst-read variant built this way (four row reads per
+# wait, fragment ring overwritten early) died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on its first launch; the variants
+# below happened to run.  Run such builds once, under `timeout`, and never in a loop.
 VARIANTS["nowaits"] = VARIANTS["nobar_novm"] + VARIANTS["noscorewait"] + VARIANTS["nopvwait"]
 VARIANTS["nowaits_norefill"] = VARIANTS["nowaits"] + VARIANTS["norefill"]
 VARIANTS["noscorereads"] = [('        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks % RD]) : "v"(aa[ks & 7]), "i"((ks >> 3) * 8192) : "memory");',
@@ -82,6 +87,15 @@ VARIANTS["diet_occ1"] = DIET + [LDSPAD]
 VARIANTS["diet_occ1_grid512"] = DIET + [GRID512, LDSPAD]
 # round 5: non-temporal queue stream of the small-batch kernel (each tile is read by exactly one workgroup)
 VARIANTS["small_nt"] = [("#define MOMA_K2_SMALL_AUX 0 ", "#define MOMA_K2_SMALL_AUX 2 ")]
+# round 5: de-synchronise the four waves of a workgroup after the end-of-iteration barrier (they run the same stream in lockstep and
+# meet at the LDS with the same ds_read_b128 of every k-step): wave w idles w x N cycles behind the barrier
+for _n in (3, 7, 15):
+    VARIANTS[f"wavestagger{_n + 1}"] = [(LOOP_END, LOOP_END.replace(
+        "            __builtin_amdgcn_s_barrier();\n",
+        "            __builtin_amdgcn_s_barrier();\n"
+        f"            if (wave >= 1) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"
+        f"            if (wave >= 2) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"
+        f"            if (wave >= 3) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"))]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()
