@@ -644,7 +644,10 @@ def main():
                                    f"MOMA_SE={os.environ.get('MOMA_SE', 'hip')}), KD kernels {a.moma_prec}",
                        "global_batch": world * a.batch_size, "parallelism": f"dp{world}", "queue": "per-rank",
                        "step_graphs": {"enabled": bool(a.graph_student), "timed_steps_replayed": int(replayed),
-                                       "DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}},
+                                       "DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"),
+                                       "host_pacing": os.environ.get("MOMA_GRAPH_THROTTLE", "1") == "1",
+                                       "HSA_KERNARG_POOL_SIZE": os.environ.get("HSA_KERNARG_POOL_SIZE")},
+                       "queue_prefetch_sweep": bool(a.prefetch_queue)},
             "roofline": roof,
         }
         if distributed:      # what the N>1 line was measured with (the driver checks it against its own launch)
