@@ -129,10 +129,19 @@ int moma_infonce_logits_bwd_kq(const float* dlogits, const float* q, float* dk, 
     return MOMA_OK;
 }
 
+// Exact-fp32 policy over a bf16-STORED queue at a width the one-pass fp32 kernel takes: the queue is widened (bf16 -> fp32 is
+// exact) into the workspace and that kernel streams the copy -- 64 MB read + 128 MB written at K x d = 65536 x 512 (~35 us) in front
+// of a 378 us pass, against 807 us for the staged path with its [B,K+1] logits (round 5).  The copy lives for the call only.
+static bool f32_policy_widens_queue(int B, int d, int K, int qdtype, int prec) {
+    return prec == MOMA_PREC_F32 && qdtype == MOMA_DT_BF16 && infonce_f32_flash_supported(B, d, K, MOMA_DT_F32, prec);
+}
+
 size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int prec) {
     if (B <= 0 || d <= 0 || K <= 0) return 0;
     if (infonce_flash_supported(B, d, K, qdtype, prec)) return infonce_flash_workspace_bytes(B, d, K);
     if (infonce_f32_flash_supported(B, d, K, qdtype, prec)) return infonce_f32_flash_workspace_bytes(B, d, K);
+    if (f32_policy_widens_queue(B, d, K, qdtype, prec))
+        return align_up((size_t)K * d * sizeof(float), 256) + infonce_f32_flash_workspace_bytes(B, d, K);
     return align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256);
 }
 
@@ -171,6 +180,16 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     if (infonce_f32_flash_supported(B, d, K, qdtype, prec))      // exact fp32, fp32 queue: one pass, no [B,K+1] logits
     {
         const int rc = hip_rc(launch_infonce_f32_flash(q, k, (const float*)queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, st,
+                                                       (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
+        if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
+        return rc;
+    }
+    if (f32_policy_widens_queue(B, d, K, qdtype, prec)) {
+        if (misaligned(queue, 16)) return MOMA_E_ALIGN;
+        float* wide = (float*)workspace;
+        void* ws2 = (char*)workspace + align_up((size_t)K * d * sizeof(float), 256);
+        MOMA_TRY(launch_widen_bf16(queue, wide, (size_t)K * d, st));
+        const int rc = hip_rc(launch_infonce_f32_flash(q, k, wide, B, d, K, inv_T, loss_rows, lse, top1, dq, ws2, st,
                                                        (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
         if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
         return rc;

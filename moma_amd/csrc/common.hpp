@@ -92,6 +92,7 @@ hipError_t launch_pos_grad_init(const float* dlogits, long ld, const float* k, f
 hipError_t launch_enqueue(void* queue, const float* rows, int n, int64_t index, int K, int d, int qdtype, hipStream_t st);
 hipError_t launch_enqueue_mirror(float* queue, void* mirror, const float* rows, int n, int64_t index, int K, int d, hipStream_t st);
 hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t st);
+hipError_t launch_widen_bf16(const void* src, float* dst, size_t n, hipStream_t st);      // bf16 -> fp32, n elements (src 16-B aligned)
 hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks, float m, float om, hipStream_t st);
 
 // ---- infonce_fused.hip (one-pass flash-style kernel) ----------------------------------------------

@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__
     asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));          // keep the loads
 }
 
+// bf16 -> fp32 (exact) of a whole queue: the exact-fp32 K2 policy over a bf16-stored queue streams the widened copy (api.hip)
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, size_t n8,
+                                                         const bf16_raw* __restrict__ tail_src, float* __restrict__ tail_dst, int ntail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        dst[2 * i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                                 __uint_as_float(v.y & 0xffff0000u));
+        dst[2 * i + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                                     __uint_as_float(v.w & 0xffff0000u));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail_dst[threadIdx.x] = bf16_to_f32(tail_src[threadIdx.x]);
+}
+
 // ema = fma(1-m, p, ema*m) over a table of tensors   (learning/contrast_trainer.py:207-211)
 __global__ __launch_bounds__(256) void ema_kernel(const int64_t* __restrict__ table, int n_tensors, float m, float om) {
     const int64_t blk = blockIdx.x;
@@ -133,6 +146,18 @@ hipError_t launch_prefetch(const void* p, size_t bytes, hipStream_t st) {
     size_t blocks = (n16 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)p, n16);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_bf16(const void* src, float* dst, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const size_t n8 = n / 8;
+    size_t blocks = (n8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const bf16_raw* s16 = (const bf16_raw*)src;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4*)src, (float4*)dst, n8, s16 + n8 * 8,
+                       dst + n8 * 8, (int)(n - n8 * 8));
     return hipGetLastError();
 }
 
