@@ -84,7 +84,8 @@ int moma_enqueue_mirror(float* queue, void* mirror_bf16, const float* rows, int 
 /* Cache hint for K2: streams `bytes` of the queue once (16-B loads, data dropped) so that it sits in the 256 MiB memory-side
  * Infinity Cache when moma_infonce_fused reads it next.  In the training step the K x d queue was last touched a whole step
  * (gigabytes of activations) ago; issued on a second stream under the latency-bound attention launches that precede K2, the
- * sweep costs no step time and K2 then runs at its cache-resident rate.  Purely a performance hint: no result depends on it. */
+ * sweep costs no step time and K2 then runs at its cache-resident rate.  Purely a performance hint: no result depends on it.
+ * (Round 5: the training loop no longer issues it by default -- a second read of the queue per step for 0.6 us of K2 at B = 256.) */
 int moma_queue_prefetch(const void* queue, size_t bytes, moma_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -101,7 +102,9 @@ int moma_queue_prefetch(const void* queue, size_t bytes, moma_stream_t stream);
  *       loss_rows[b] = lse[b] - out[b,0]                  (loss_kd = mean_b loss_rows[b])
  *       top1[b]      = 1 if out[b,0] >= max_j out[b,j] else 0
  *       dq[b,:]      = d(sum_b loss_rows)/dq_b = ((p_b0-1)*k_b + sum_j p_bj*queue_j)*inv_T
- *     dq may be NULL (forward only).  workspace: moma_infonce_fused_workspace_bytes().
+ *     dq may be NULL (forward only).  workspace: moma_infonce_fused_workspace_bytes() -- it depends on (qdtype, prec): under
+ *     prec = fp32 with a bf16-stored queue it includes room for a widened (fp32, exact) copy of the queue, made and dropped inside
+ *     the call, at the widths the one-pass fp32 kernel takes.
  * ------------------------------------------------------------------------------------------- */
 int moma_infonce_logits(const float* q, const float* k, const void* queue, float* out,
                         int B, int d, int K, float inv_T, int qdtype, int prec, moma_stream_t stream);
