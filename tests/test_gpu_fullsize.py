@@ -103,7 +103,8 @@ def test_ema_fixed_point_and_copy(env):
                                           (40, 1280, 1_700_000, "bf16"),      # wide rows: two passes + the P scratch
                                           (4, 2048, 1_100_000, "bf16"),       # two register passes of Q
                                           (130, 512, 4_300_000, "fp32"),      # exact-fp32 one pass over an fp32 queue (8.8 GB)
-                                          (20, 1280, 1_700_000, "fp32")])     # ... segment-streamed
+                                          (20, 1280, 1_700_000, "fp32"),      # ... segment-streamed
+                                          (130, 512, 4_300_000, "fp32/bf16")])  # exact fp32 over a bf16-STORED queue: widened in the workspace
 def test_queue_beyond_2_31_elements(Bq, d, Kq, prec):
     """Maximum sizes: a queue of more than 2^31 elements (row offsets past 32 bits everywhere: LDS-DMA source addresses, the
     P scratch of the wide path, the enqueue's slot address).  K2's loss / dq against fp64 torch on the same bf16 queue values, then
@@ -115,7 +116,8 @@ def test_queue_beyond_2_31_elements(Bq, d, Kq, prec):
     g = torch.Generator(device="cuda").manual_seed(Kq % 1000 + d)
     q = torch.nn.functional.normalize(torch.randn(Bq, d, device="cuda", generator=g)).requires_grad_(True)
     k = torch.nn.functional.normalize(q.detach() + 0.3 * torch.randn(Bq, d, device="cuda", generator=g))
-    qdt = torch.bfloat16 if prec == "bf16" else torch.float32
+    qdt = torch.bfloat16 if prec in ("bf16", "fp32/bf16") else torch.float32
+    prec = prec.split("/")[0]
     queue = torch.empty(Kq, d, device="cuda", dtype=qdt)
     step = 1 << 18
     for i in range(0, Kq, step):                                # (normalised in pieces: no second copy of the whole queue)
