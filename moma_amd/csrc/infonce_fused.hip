@@ -1763,6 +1763,7 @@ __global__ __launch_bounds__(256) void infonce_slab_stats_kernel(const float* __
 // thread and chunk; the chunk-groups are summed through LDS in a fixed order (bitwise reproducible).
 constexpr int COMBINE_MAX_CHUNKS = 1024;
 constexpr int SMALL_B_MAX = 64;      // batches up to this take infonce_small_kernel (with dq)
+template <int TB = 1>
 __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q, const float* __restrict__ k,
                                                      int B, int D, float inv_T, int nchunk, int Bpad,
                                                      const uint4* __restrict__ o_part,
@@ -1885,6 +1886,66 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
     const int col = tid & 31, cgrp = tid >> 5;
     // wide queues (D > 512) keep one partial buffer per column slab of 512 (the last one narrower), `slab_stride` uint4 apart
     const int n = col;
+    if constexpr (TB > 1) {
+        // ---- wide rows: the TB column tiles of a block with ALL their partial loads in flight at once instead of one dependent
+        //      round trip per tile (own instantiation: the d <= 512 combine keeps its register count).  Measured (round 5, d = 1280):
+        //      16.4 -> 15.6 - 15.9 us per combine -- the tiles were not what the wide-row combine waits for; its per-block row
+        //      statistics are (1 tile per block, 4x the blocks: 22.3 us; 8 tiles: 21.7).
+        if (tpb == TB && nparts <= 64) {
+            const int c0 = blockIdx.y * TB;
+            uint4 v[TB][8];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int c = min(c0 + t, D / 32 - 1);                   // (a block's surplus tiles re-read the last one; not stored)
+                const int sl = c >> 4, cl = c & 15;
+                const int nct = min(16, D / 32 - 16 * sl);
+                const long wb_stride = (long)nct * 2 * 64;
+                const long chunk_stride = (long)(Bpad / 32) * wb_stride;
+                const uint4* src = o_part + sl * slab_stride + (long)wb * wb_stride + (cl * 2 + g) * 64 + h * 32 + n;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[t][u] = (cgrp + 8 * u < nparts) ? src[(long)(cgrp + 8 * u) * chunk_stride] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int c = c0 + t;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ck = cgrp + 8 * u;
+                    if (ck < nparts) {
+                        const float4 w0 = *reinterpret_cast<const float4*>(&wts[ck][0]);
+                        const float4 w1 = *reinterpret_cast<const float4*>(&wts[ck][4]);
+                        const uint4 x = v[t][u];
+                        acc[0] = fmaf(w0.x, __uint_as_float(x.x << 16), acc[0]);
+                        acc[1] = fmaf(w0.y, __uint_as_float(x.x & 0xffff0000u), acc[1]);
+                        acc[2] = fmaf(w0.z, __uint_as_float(x.y << 16), acc[2]);
+                        acc[3] = fmaf(w0.w, __uint_as_float(x.y & 0xffff0000u), acc[3]);
+                        acc[4] = fmaf(w1.x, __uint_as_float(x.z << 16), acc[4]);
+                        acc[5] = fmaf(w1.y, __uint_as_float(x.z & 0xffff0000u), acc[5]);
+                        acc[6] = fmaf(w1.z, __uint_as_float(x.w << 16), acc[6]);
+                        acc[7] = fmaf(w1.w, __uint_as_float(x.w & 0xffff0000u), acc[7]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) accs[cgrp][i][col] = acc[i];
+                __syncthreads();
+                {
+                    const int i = cgrp;
+                    const int b = row_of(i);
+                    if (b < B && c < D / 32) {
+                        float a = accs[0][i][col];
+#pragma unroll
+                        for (int u = 1; u < 8; ++u) a += accs[u][i][col];   // (the order of the sequential walk: same bits)
+                        const long o = (long)b * D + c * 32 + col;
+                        dq[o] = (rowc[i][1] * k[o] + a * rowc[i][0]) * inv_T;
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
     for (int c = blockIdx.y * tpb; c < min((int)(blockIdx.y + 1) * tpb, D / 32); ++c) {
     const int sl = c >> 4, cl = c & 15;
     const int nct = min(16, D / 32 - 16 * sl);
@@ -1939,6 +2000,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
     }
 }
 
+template <int TB>
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                int B, int D, float inv_T, int nchunk, int Bpad,
                                                                const uint4* __restrict__ o_part,
@@ -1949,8 +2011,8 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                int32_t* __restrict__ top1, float* __restrict__ dq,
                                                                long slab_stride, int cg, int tpb,
                                                                const float* __restrict__ ref_part) {
-    infonce_combine_body(q, k, B, D, inv_T, nchunk, Bpad, o_part, m_part, l_part, x_part, loss_rows, lse_out, top1, dq, slab_stride,
-                         cg, tpb, ref_part);
+    infonce_combine_body<TB>(q, k, B, D, inv_T, nchunk, Bpad, o_part, m_part, l_part, x_part, loss_rows, lse_out, top1, dq, slab_stride,
+                             cg, tpb, ref_part);
 }
 
 // ---- several InfoNCE terms in ONE sweep (the dual-queue memories MoCoST / MoCoSSTT, reference MoMA/mem_moco.py:165-253:
@@ -2196,7 +2258,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_SMALL_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(Bp / 8, d / 32), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+        hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(Bp / 8, d / 32), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
                               d, inv_T, nwg, Bp, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
         return hipGetLastError();
     }
@@ -2296,9 +2358,12 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         }
         if (ev_end && !ev_on_dispatch) (void)hipEventRecord(ev_end, st);      // (slab passes: recorded behind the last pass)
         {
-            int tpb = 4;                                           // (measured at d = 1280: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call)
+            // column tiles per block (measured at d = 1280, B = 256: 1 / 2 / 4 / 8 -> 157 / 152 / 150 / 151 us per call; B = 64, where 4
+            // leaves only 80 live workgroups: 1 -> 22.3 us for the combine against 16.5 at 4 -- every block repeats the row
+            // statistics, and those, not the tiles, are what the wide-row combine spends its time on)
+            int tpb = 4;
             const int nty = dq ? (d / 32 + tpb - 1) / tpb : 1;
-            hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, nty), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+            hipExtLaunchKernelGGL((infonce_combine_kernel<4>), dim3(p.Bpad / 8, nty), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
                                   d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq,
                                   (long)(slab_bytes / 16), cg, tpb, wide_ref);
         }
@@ -2324,7 +2389,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // (ev_call_end rides on the combine's dispatch: ev_begin .. ev_call_end spans the call's kernels, dispatch to dispatch)
-    hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,
+    hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,
                           k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
     return hipGetLastError();
 }

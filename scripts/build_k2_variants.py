@@ -44,7 +44,7 @@ VARIANTS["scoreacc_agpr"] = [
      '                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(x) : "v"(kf[ks % RD]), "v"(qf[ks]));'),
 ]
 # combine experiments: two column tiles per block (half the blocks, the row statistics repeated half as often) / no q.k dot in the combine
-COMB_OLD = ('    hipExtLaunchKernelGGL(infonce_combine_kernel, dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,\n'
+COMB_OLD = ('    hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,\n'
             '                          k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);')
 VARIANTS["comb_tpb2"] = [(COMB_OLD, COMB_OLD.replace("dq ? d / 32 : 1", "dq ? d / 64 : 1").replace("0L, 1, 1, m_part", "0L, 1, 2, m_part"))]
 VARIANTS["comb_tpb4"] = [(COMB_OLD, COMB_OLD.replace("dq ? d / 32 : 1", "dq ? d / 128 : 1").replace("0L, 1, 1, m_part", "0L, 1, 4, m_part"))]
@@ -96,6 +96,9 @@ for _n in (3, 7, 15):
         f"            if (wave >= 1) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"
         f"            if (wave >= 2) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"
         f"            if (wave >= 3) asm volatile(\"s_nop {_n}\" ::: \"memory\");\n"))]
+# round 5: column tiles per block of the wide-row combine
+for _t in (2, 8, 10):
+    VARIANTS[f"wcomb_tpb{_t}"] = [("            int tpb = 4;\n", f"            int tpb = {_t};\n")]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()

@@ -17,7 +17,7 @@ for r in rows:
     calls, avg = int(r["Calls"]), float(r["AverageNs"]) / 1e3
     per_call = avg * calls / 25.0            # 5 warm-up + 20 timed calls
     tot += per_call
-    print("    %-60s calls %3d  avg %8.2f us  per K2 call %8.2f us" % (r["Name"].split("(")[0][-60:], calls, avg, per_call))
+    print("    %-60s calls %3d  avg %8.2f us  per K2 call %8.2f us" % (r["Name"].replace("void ", "").replace("moma::(anonymous namespace)::", "moma::").split("(")[0][:60], calls, avg, per_call))
 print("    sum of kernel time per K2 call: %.2f us" % tot)
 PY
 done
