@@ -41,6 +41,32 @@ __device__ __forceinline__ float other_half(float v) {
     return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// Reductions over the 32 lanes of a wave HALF (lanes 0-31 / 32-63), result in every lane, without LDS: four DPP rotations inside
+// the 16-lane rows (x op= ror 8, 4, 2, 1: a butterfly, so every lane of a row ends with the same bits) and one v_permlane16_swap
+// across the two rows of the half.  __shfl_xor is a ds_bpermute each -- five dependent LDS round trips per reduction.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float half32_sum(float v) {
+    v += dpp_row<0x128>(v);            // row_ror:8
+    v += dpp_row<0x124>(v);            // row_ror:4
+    v += dpp_row<0x122>(v);            // row_ror:2
+    v += dpp_row<0x121>(v);            // row_ror:1
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // r[0] = rows {0, 0, 2, 2}, r[1] = rows {1, 1, 3, 3}
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half32_max(float v) {
+    v = fmaxf(v, dpp_row<0x128>(v));
+    v = fmaxf(v, dpp_row<0x124>(v));
+    v = fmaxf(v, dpp_row<0x122>(v));
+    v = fmaxf(v, dpp_row<0x121>(v));
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

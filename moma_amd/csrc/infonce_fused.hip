@@ -1786,16 +1786,8 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
                                                                          // partials are not even written by the passes over the queue)
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     auto row_of = [&](int i) { return wb * 32 + opart_row(g, h, i >> 1, i & 1); };
-    auto sum32 = [](float v) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-    };
-    auto max32 = [](float v) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-        return v;
-    };
+    auto sum32 = [](float v) { return half32_sum(v); };          // (DPP + one permlane swap: no LDS round trips)
+    auto max32 = [](float v) { return half32_max(v); };
     const int nparts = (nchunk + cg - 1) / cg;                            // partial buffers: one per chunk (group)
     // (requesting the first batch of O partials ahead of the statistics -- they do not depend on them -- was slower, 14.4 vs
     //  10.3 us: 64 more live registers halve the waves per CU of a kernel that lives on bytes in flight)
@@ -1809,15 +1801,22 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
         // (the kernel is latency-bound: 6.5 us of its 13.9 were this prologue).
         constexpr int MC = 8;                      // (256 chunks -- the small-batch plan -- still take the one-round-trip path)
         const bool small = nchunk <= 32 * MC;
-        float mv[MC], xv[MC], lv[MC];
-#pragma unroll
-        for (int i = 0; i < MC; ++i) {
-            const int c = l32 + 32 * i;
-            const bool ok = small && c < nchunk;
-            const long o = (long)(ok ? c : 0) * Bpad + bb;
-            mv[i] = ok ? m_part[o] : NEG_BIG;
-            xv[i] = ok ? x_part[o] : NEG_BIG;
-            lv[i] = ok ? l_part[o] : 0.f;
+        // Round 5: the (chunk, row) statistics come in by COALESCED loads.  Lane = (row, 32 chunks) gathers -- one 4-byte value per
+        // lane, 1 KB apart: 32 sectors per wave instruction, 48 instructions per block, every sector asked for by all four waves --
+        // took 3.2 us of the block's 9.7 (in-kernel stamps, scripts/diag_combine_stamps.py).  The 8 rows of a block are two runs of
+        // 4 consecutive rows (opart_row: base + {0..3} and base + {8..11}), so a chunk's 8 values are TWO float4: 6 * nchunk loads
+        // per block, 3 per thread at 128 chunks, transposed through the part of wts[] that 256 chunks leave unused.
+        float* stat = &wts[256][0];                // [3 arrays][8 rows][256 chunks] floats = rows 256 .. 1023 of wts (small only)
+        if (small) {
+            const int rowbase = wb * 32 + 16 * g + 4 * h;                 // = row_of(0); rows +0..3 and +8..11
+            const int per = 2 * nchunk;
+            for (int idx = tid; idx < 3 * per; idx += 256) {
+                const int a = idx / per, rem = idx - a * per, c = rem >> 1, hf = rem & 1;
+                const float* src = (a == 0 ? m_part : a == 1 ? x_part : l_part) + (long)c * Bpad + rowbase + 8 * hf;
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                float* dst = stat + (a * 8 + 4 * hf) * 256 + c;
+                dst[0] = v.x; dst[256] = v.y; dst[512] = v.z; dst[768] = v.w;
+            }
         }
         float s = 0.f;                                                   // positive logit
 #pragma unroll 4
@@ -1825,6 +1824,18 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
             const float4 qa = *reinterpret_cast<const float4*>(q + (long)bb * D + c);
             const float4 ka = *reinterpret_cast<const float4*>(k + (long)bb * D + c);
             s = fmaf(qa.x, ka.x, s); s = fmaf(qa.y, ka.y, s); s = fmaf(qa.z, ka.z, s); s = fmaf(qa.w, ka.w, s);
+        }
+        if (small) __syncthreads();                                      // (block-uniform) the transposed statistics are in LDS
+        float mv[MC], xv[MC], lv[MC];
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int c = l32 + 32 * i;
+            const bool ok = small && c < nchunk;
+            const int o = ok ? c : 0;
+            // (rows past B inside a live group read their own -- unused -- entries; nothing of them reaches an output)
+            mv[i] = ok ? stat[(0 * 8 + rr) * 256 + o] : NEG_BIG;
+            xv[i] = ok ? stat[(1 * 8 + rr) * 256 + o] : NEG_BIG;
+            lv[i] = ok ? stat[(2 * 8 + rr) * 256 + o] : 0.f;
         }
         const float s0 = sum32(s) * inv_T;
         const float s0l = s0 * LOG2E;

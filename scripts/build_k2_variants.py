@@ -99,6 +99,43 @@ for _n in (3, 7, 15):
 # round 5: column tiles per block of the wide-row combine
 for _t in (2, 8, 10):
     VARIANTS[f"wcomb_tpb{_t}"] = [("            int tpb = 4;\n", f"            int tpb = {_t};\n")]
+# round 5: wall-clock stamps inside the combine kernel (one lane per workgroup -> a __device__ array read back by
+# moma_debug_combine_stamps; scripts/diag_combine_stamps.py prints the timeline).  Diagnostic build only.
+VARIANTS["combine_stamps"] = [
+    ("namespace moma {\nnamespace {\n\ntypedef __attribute__((ext_vector_type(4))) short s16x4;",
+     "namespace moma {\n__device__ unsigned long long g_cmb_stamps[4096 * 8];\nnamespace {\n\ntypedef __attribute__((ext_vector_type(4))) short s16x4;"),
+    ("    const int tid = threadIdx.x;\n    const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;\n",
+     "    const int tid = threadIdx.x;\n    const int wb = blockIdx.x >> 2, g = (blockIdx.x >> 1) & 1, h = blockIdx.x & 1;\n"
+     "    int stamp_i = 0;\n"
+     "    auto stamp = [&]() __attribute__((always_inline)) {\n"
+     "        unsigned long long tt;\n"
+     "        asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(tt) :: \"memory\");\n"
+     "        const int wgid = blockIdx.y * gridDim.x + blockIdx.x;\n"
+     "        if (tid == 0 && wgid < 4096) g_cmb_stamps[wgid * 8 + stamp_i] = tt;\n"
+     "        ++stamp_i;\n"
+     "    };\n"
+     "    stamp();\n"),
+    ("    if (dq == nullptr) return;\n    __syncthreads();                                                     // wts[][], rowc[][] complete\n",
+     "    if (dq == nullptr) return;\n    stamp();\n    __syncthreads();                                                     // wts[][], rowc[][] complete\n    stamp();\n"),
+    ("#pragma unroll\n    for (int i = 0; i < 8; ++i) accs[cgrp][i][col] = acc[i];\n    __syncthreads();\n    {\n        const int i = cgrp;                                              // 8 rows x 32 columns of output, one per thread",
+     "    stamp();\n#pragma unroll\n    for (int i = 0; i < 8; ++i) accs[cgrp][i][col] = acc[i];\n    __syncthreads();\n    {\n        const int i = cgrp;                                              // 8 rows x 32 columns of output, one per thread"),
+    ("    __syncthreads();                                                     // accs[] is reused by the next column tile\n",
+     "    stamp();\n    __syncthreads();                                                     // accs[] is reused by the next column tile\n"),
+    ("}  // namespace moma\n", "}  // namespace moma\nextern \"C\" int moma_debug_combine_stamps(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(moma::g_cmb_stamps), sizeof(unsigned long long) * 4096 * 8); }\n"),
+]
+# round 5: the split-K partials of the one-pass kernel stored write-through (sc1) instead of left dirty in the XCD's L2 for the
+# kernel-end write-back that the combine's first loads then wait for (combine timeline: 4.9 us until its row statistics are in)
+SC1 = ("                dst[(c * 2 + g) * 64] = v;     // (non-temporal stores: same kernel time, +3 us on the combine that reads them back)",
+       "                { typedef unsigned u32x4_t __attribute__((ext_vector_type(4))); const u32x4_t vv = {v.x, v.y, v.z, v.w};\n"
+       "                  asm volatile(\"global_store_dwordx4 %0, %1, off sc1\" :: \"v\"(dst + (c * 2 + g) * 64), \"v\"(vv) : \"memory\"); }")
+VARIANTS["opart_sc1"] = [SC1]
+VARIANTS["opart_sc0sc1"] = [(SC1[0], SC1[1].replace("off sc1", "off sc0 sc1"))]
+VARIANTS["opart_sc1_stamps"] = [SC1] + VARIANTS["combine_stamps"]
+VARIANTS["combine_stamps2"] = VARIANTS["combine_stamps"] + [
+    ("        float s = 0.f;                                                   // positive logit\n",
+     "        stamp();\n        float s = 0.f;                                                   // positive logit\n"),
+    ("        const float s0 = sum32(s) * inv_T;\n", "        stamp();\n        const float s0 = sum32(s) * inv_T;\n"),
+]
 names = sys.argv[1:] or list(VARIANTS)
 os.makedirs(OUT, exist_ok=True)
 text = open(SRC).read()
