@@ -108,3 +108,30 @@ def test_every_entry_point_rejects_null_pointers_and_negative_sizes(lib_path):
             assert fn(*args(ptr, 0)) <= 0, (name, "zero sizes")       # (an empty job -- e.g. an EMA table without tensors -- may be a no-op)
         checked += 1
     assert checked >= 20
+
+
+def test_k2_workspace_sizes_follow_the_plan(lib_path):
+    """moma_infonce_fused_workspace_bytes (host arithmetic only): the split-K partials of the one-pass paths dominate, so the size
+    follows the plan -- one partial per chunk, fewer chunks for short passes (round 5) -- and the exact-fp32 policy over a bf16-stored
+    queue adds room for the widened copy of the queue."""
+    lib = ctypes.CDLL(lib_path)
+    f = lib.moma_infonce_fused_workspace_bytes
+    f.restype = ctypes.c_size_t
+    f.argtypes = [ctypes.c_int] * 5
+    from moma_amd import ops                          # (dtype / precision codes of include/moma_hip.h)
+    bf, f32, pbf, pf32 = ops.DT_BF16, ops.DT_F32, ops.PREC_BF16, ops.PREC_F32
+    MB = 1 << 20
+    # bench shape: 128 chunks x 256 rows x 512 bf16 of partials = 32 MiB (+ statistics, + the packed q)
+    big = f(256, 512, 65536, bf, pbf)
+    assert 32 * MB < big < 34 * MB
+    # the reference's run-script shape: 128 chunks (round 5; one workgroup per CU would be 256) of 128 padded rows for the
+    # forward-only pass of the general kernel = 16 MiB; the small-batch kernel with dq uses half of it
+    ref = f(64, 512, 16384, bf, pbf)
+    assert 16 * MB <= ref < 17 * MB and ref < f(64, 512, 65536, bf, pbf)
+    # a short pass over narrow rows is cut into fewer chunks than a long one: less workspace, never zero
+    assert 0 < f(256, 128, 16384, bf, pbf) < f(256, 128, 65536, bf, pbf)
+    # exact fp32 over a bf16 queue: the widened queue (K x d x 4) rides in the workspace
+    wide = f(256, 512, 65536, bf, pf32)
+    assert wide >= 65536 * 512 * 4 + f(256, 512, 65536, f32, pf32)
+    # invalid shapes: 0
+    assert f(0, 512, 65536, bf, pbf) == 0 and f(256, 512, 0, bf, pbf) == 0
