@@ -256,15 +256,34 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // MFMAs, so the pipelined kernel requests only two tiles up front and fills the rest of the ring from the first tile's
     // scores (tile t0+2) and the first loop iteration (tile t0+3), exactly like the steady-state refills.
     constexpr int PRO = (WITH_DQ && MODE == 0) ? 2 : MOMA_K2_PRO;
-    auto issue_ring = [&](auto first_pass, int jb, int je) __attribute__((always_inline)) {
+    static_assert(PRO == 2 || PRO == NBUF, "the non-pipelined loops find the whole ring requested");
+    // The prologue's requests and its first wait branch on the SAME wave-uniform predicates, nested the same way: on every
+    // path through the two the wait's count is the number of pieces that path has issued behind Q and tile t0 -- which is what
+    // scripts/audit_isa.py checks on the compiled code (it walks every path and knows only that the same comparison of the
+    // same registers gives the same answer).  Tile t0 always exists.
+    auto issue_ring = [&](auto first_pass) __attribute__((always_inline)) {
         int tb = t0;
         asm volatile("" : "+s"(tb));                   // (opaque: the two passes do not share hoisted source addresses)
 #pragma unroll
-        for (int j = 0; j < NBUF; ++j) {
-            if (j >= jb && j < je && j < npro) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+        for (int j = 0; j < PRO; ++j) {
+            if (npro > j) dma_tile<D>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
         }
     };
-    issue_ring(std::true_type{}, 0, PRO);
+    // Q and tile t0 have landed; the other tiles of the prologue stay in flight
+    auto wait_first_tile = [&]() __attribute__((always_inline)) {
+        if (npro > 1) {
+            if constexpr (PRO > 2) {
+                if (npro > 2) {
+                    if (npro > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+                } else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            } else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    issue_ring(std::true_type{});
 
     f32x16 O[WITH_DQ ? NCT : 1];
     float l_run = 0.f, mx = NEG_BIG;
@@ -546,7 +565,7 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     // -- a full drain of the tile ring -- in front of the first pass's first softmax)
     auto run_pass = [&](auto repass_tag) __attribute__((always_inline)) {
     constexpr bool repass = decltype(repass_tag)::value;
-    if constexpr (repass) issue_ring(std::false_type{}, 0, PRO);
+    if constexpr (repass) issue_ring(std::false_type{});
     if constexpr (WITH_DQ) {
         // O = 0 as the result of an MFMA on zero operands with the inline-constant accumulator 0: 16 matrix instructions
         // issued while the first tile is on its way, instead of 256 accumulator-register writes that hipcc rematerialises
@@ -567,13 +586,12 @@ __device__ __forceinline__ void infonce_flash_body(const int id, char* smem, con
     mx = NEG_BIG;
     ovf = 0;
     // Q and tile t0 have landed (the rest of the ring stays in flight); from here on the Q registers may be read
-    wait_tiles_in_flight(min(npro, PRO) - 1);
+    wait_first_tile();
     if constexpr (MODE != 2) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
     __builtin_amdgcn_s_barrier();
-    if constexpr (PRO < NBUF && !PIPELINED) issue_ring(std::false_type{}, PRO, NBUF);
 
     if constexpr (PIPELINED) {
         // ---- software-pipelined main loop (one wave per SIMD: nothing else hides the softmax's VALU time):
@@ -806,12 +824,20 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
     }
     auto slot = [&](int t) __attribute__((always_inline)) -> char* { return smem + ((unsigned)(t - t0) & (NBUF - 1)) * TILE_BYTES; };
     const int npro = min(t1 - t0, NBUF - 1);                  // tiles requested up front: t0 .. t0+2 (t0+3 follows in tile t0's shadow)
+    // (requests and first wait branch on the same nested wave-uniform predicates, as in the one-pass kernel: scripts/audit_isa.py)
+    const bool has1 = npro > 1, has2 = npro > 2;
     auto issue_ring = [&]() __attribute__((always_inline)) {
         int tb = t0;
         asm volatile("" : "+s"(tb));
-#pragma unroll
-        for (int j = 0; j < NBUF - 1; ++j)
-            if (j < npro) dma_tile<D, MOMA_K2_SMALL_AUX>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+        auto req = [&](int j) __attribute__((always_inline)) {
+            dma_tile<D, MOMA_K2_SMALL_AUX>(dl, queue, (long)(tb + j) * KT, K, smem + j * TILE_BYTES, wave, lane);
+        };
+        static_assert(NBUF - 1 == 3, "three tiles up front");
+        req(0);
+        if (has1) {
+            req(1);
+            if (has2) req(2);
+        }
     };
     issue_ring();
 
@@ -885,7 +911,11 @@ __global__ __launch_bounds__(256, 1) void infonce_small_kernel(const uint4* __re
         l_run = 0.f;
         mx = NEG_BIG;
         ovf = 0;
-        wait_tiles_in_flight(npro - 1);                       // Q and tile t0 have landed
+        if (has1) {                                           // Q and tile t0 have landed
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s = 0; s < KS2; ++s) { asm volatile("" : "+v"(qf[0][s])); asm volatile("" : "+v"(qf[1][s])); }
         __builtin_amdgcn_s_barrier();
@@ -1319,7 +1349,9 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
             const int bfree = bi == 0 ? 2 : bi - 1;  // buffer of the previous phase: free since the last barrier
             char* rbuf = smem + bfree * PH_BYTES;
             const int rt = t + (p + 2) / NPH, rp = (p + 2) % NPH;
-            const bool refill = rt < t1;
+            // (ONE scalar for the request and for the wait that counts it: hipcc otherwise carries the flag through a vector
+            //  register and re-derives it, and scripts/audit_isa.py can no longer tell that the two branches agree)
+            const bool refill = __builtin_amdgcn_readfirstlane((int)(rt < t1)) != 0;
             {
                 const unsigned a0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)buf + a_off;
 #pragma unroll
@@ -1361,11 +1393,13 @@ __global__ __launch_bounds__(256, 1) void infonce_wide_scores_kernel(const uint4
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x));
                 if constexpr (KIND == 0) {
                     char* xb = xq_ptr(t);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 v = {x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
-                        asm volatile("global_store_dwordx4 %0, %1, off offset:%2" :: "v"(xb), "v"(v), "n"(i * 1024) : "memory");
-                    }
+                    const f32x4 v0 = {x[0], x[1], x[2], x[3]}, v1 = {x[4], x[5], x[6], x[7]}, v2 = {x[8], x[9], x[10], x[11]},
+                                v3 = {x[12], x[13], x[14], x[15]};
+                    // ONE statement, closed by the two wait states a 16-byte store needs before its data registers may be
+                    // written again: hipcc pads that hazard only behind stores it emitted itself (scripts/audit_isa.py, check c)
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:1024\n\t"
+                                 "global_store_dwordx4 %0, %3, off offset:2048\n\tglobal_store_dwordx4 %0, %4, off offset:3072\n\ts_nop 1"
+                                 :: "v"(xb), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
                 } else {
                 if ((t + 1) * KT > K) {
 #pragma unroll
@@ -1518,52 +1552,49 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 sx[SD][2];
     const unsigned xlane = lane * 32;
-    auto load_scores = [&](int t, u32x4 (&d)[2]) __attribute__((always_inline)) {
+    // Every request of this kernel is UNCONDITIONAL, so that every wait has a constant count (what scripts/audit_isa.py can
+    // prove on the compiled code: a count that follows how many tiles are left cannot be checked path by path).  A request
+    // past the group's last tile (`keep` = 0) re-reads ONE 16-byte piece of the last tile's P and keys -- every lane at the same
+    // address: one cache line per instruction -- into registers and a ring slot that nothing reads any more.
+    auto load_scores = [&](int t, u32x4 (&d)[2], unsigned keep) __attribute__((always_inline)) {
         const char* xb = reinterpret_cast<const char*>(ps) + ((long)wb * ntiles + t) * 2048;          // wave-uniform
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
-                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(xlane), "s"(xb) : "memory");
+                     : "=&v"(d[0]), "=&v"(d[1]) : "v"(xlane & keep), "s"(xb) : "memory");
     };
     // ---- keys of tile t: wave w issues row group w (4 rows) of both segments (of segment 0 twice when the range has one)
     const int rl = lane >> 4, s16 = lane & 15;
     const unsigned term0 = (unsigned)(rl * pitch + ((s16 ^ (rl << 2)) << 4));
     const unsigned voff = term0 ^ (unsigned)((w & 3) << 4);
     const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
-    auto dma_tile = [&](int t, unsigned lds_slot) __attribute__((always_inline)) {
+    auto dma_tile = [&](int t, unsigned lds_slot, unsigned keep) __attribute__((always_inline)) {
         const long key0 = (long)t * KT;
         const unsigned dst = lds_slot + w * 1024;
         const int seg1 = ncs == 2 ? 256 : 0;        // (one-segment range: the second piece repeats the first into the unused half)
         if (key0 + KT <= K) {
             const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + (cb * 256 + w * 4 * (int)pitch);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff & keep), "s"(src), "s"(dst) : "memory");
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(voff), "s"(src + seg1), "s"(dst + 8192) : "memory");
+                         :: "v"(voff & keep), "s"(src + seg1), "s"(dst + 8192) : "memory");
         } else {                                    // the queue's last, partial tile: clamp rows past K (their P is 0)
             const int row = min(w * 4 + rl, (int)(K - 1 - key0));
             const unsigned off = voff - (unsigned)rl * pitch + (unsigned)row * pitch;
             const char* src = reinterpret_cast<const char*>(queue) + key0 * (long)pitch + cb * 256;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off & keep), "s"(src), "s"(dst) : "memory");
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(off), "s"(src + seg1), "s"(dst + 8192) : "memory");
+                         :: "v"(off & keep), "s"(src + seg1), "s"(dst + 8192) : "memory");
         }
     };
-    auto wait_younger_tiles = [&](int j) __attribute__((always_inline)) {          // tiles requested after the one awaited
-        switch (j) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPT) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPT) : "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPT) : "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * OPT) : "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * OPT) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * OPT) : "memory"); break;
-        }
+    static_assert(SD >= 2, "tile t+1 is awaited with SD - 1 younger requests in flight");
+    __builtin_assume(t0 < t1);                          // (no zero-trip copy of the tile loop: grp < ngroups has tiles)
+    auto request = [&](int t, u32x4 (&d)[2], unsigned lds_slot) __attribute__((always_inline)) {
+        const bool real = t < t1;
+        const unsigned keep = real ? ~0u : 0u;
+        const int te = real ? t : t1 - 1;               // (t0 < t1: the group has at least one tile)
+        load_scores(te, d, keep);
+        dma_tile(te, lds_slot, keep);
     };
-    static_assert(SD >= 2 && SD <= 7, "wait_younger_tiles covers up to 6 younger tiles");
 #pragma unroll
-    for (int j = 0; j < SD; ++j)
-        if (t0 + j < t1) {
-            load_scores(t0 + j, sx[j]);
-            dma_tile(t0 + j, lds0 + j * SLOT);
-        }
+    for (int j = 0; j < SD; ++j) request(t0 + j, sx[j], lds0 + j * SLOT);
 
     f32x16 O[2][4];
     {
@@ -1601,26 +1632,21 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
         pa[1] = __builtin_bit_cast(bf16x8, u32x4{wv[4], wv[5], wv[6], wv[7]});
     };
     bf16x8 pa[2];
-    wait_younger_tiles(max(min(t0 + SD - 1, t1 - 1) - t0, 0));           // tile t0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SD - 1) * OPT) : "memory");         // tile t0 landed
     asm volatile("" : "+v"(sx[0][0]), "+v"(sx[0][1]));
     make_p(sx[0], t0, pa);
     __builtin_amdgcn_s_barrier();
 
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     int slot_cur = 0;
-#pragma unroll 1
-    for (int tb = t0; tb < t1; tb += SD) {
-#pragma unroll
-        for (int j = 0; j < SD; ++j) {                                    // (unrolled: the score ring is indexed statically)
-            const int t = tb + j;
-            if (t < t1) {
+    // one tile; `jc` = its place in the score-register ring (indexed statically: the loop below is unrolled SD times)
+    auto tile_step = [&](const int t, auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            {
                 // tile t+SD: scores into the registers consumed last iteration, keys into the slot freed by the last barrier
                 {
                     const int slot_free = slot_cur >= NB - SD ? slot_cur - (NB - SD) : slot_cur + SD;
-                    if (t + SD < t1) {
-                        load_scores(t + SD, sx[j]);
-                        dma_tile(t + SD, lds0 + slot_free * SLOT);
-                    }
+                    request(t + SD, sx[j], lds0 + slot_free * SLOT);
                 }
                 // O += P(t) . K_tile: column tile ct = 4*seg + c; its 4 transposed reads run PF column tiles ahead
                 const unsigned lb = lds0 + slot_cur * SLOT + b_off;
@@ -1635,7 +1661,6 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(a1), "i"(6144) : "memory");
                     (void)sgi;
                 };
-                const int nct = 4 * ncs;                                  // 4 or 8 column tiles (wave-uniform)
                 // (the second segment's reads take their 8 KiB from the immediate offset: separate statements per segment)
                 auto issue_seg = [&](int ct) __attribute__((always_inline)) {
                     if ((ct >> 2) == 0) issue(ct);
@@ -1649,22 +1674,27 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(k4[3]) : "v"(a1), "i"(8192 + 6144) : "memory");
                     }
                 };
-#pragma unroll
-                for (int ct = 0; ct < PF; ++ct) issue_seg(ct);
-                // tile t+1 (keys and scores, requested two iterations ago) has landed by now; the tiles requested after it stay
-                // in flight.  P(t+1) is formed in the shadow of this tile's MFMAs, 4 (or 2) scores per column tile.
-                wait_younger_tiles(max(min(t + SD, t1 - 1) - (t + 1), 0));
-                u32x4 (&nx)[2] = sx[(j + 1) % SD];
-                asm volatile("" : "+v"(nx[0]), "+v"(nx[1]));
                 bf16x8 pn[2];
-                if (t + 1 < t1) make_p(nx, t + 1, pn);                     // (VALU work under this tile's MFMAs; no tail masking:
+                // ALWAYS 8 column tiles: the last range of an odd NSEG has one segment, its second half of the slot holds a repeat
+                // of the first (dma_tile) and the four extra column tiles are computed and not stored -- a read-ahead count that
+                // follows a run-time number of column tiles cannot be checked path by path (scripts/audit_isa.py), and a second
+                // copy of the sweep does not fit the 256 registers of two waves per SIMD.
+                auto sweep_cols = [&](auto nct_c) __attribute__((always_inline)) {
+                    constexpr int NCTC = decltype(nct_c)::value;
+#pragma unroll
+                    for (int ct = 0; ct < PF; ++ct) issue_seg(ct);
+                    // tile t+1 (keys and scores, requested two iterations ago) has landed by now; the tiles requested after it stay
+                    // in flight.  P(t+1) is formed in the shadow of this tile's MFMAs, 4 (or 2) scores per column tile.
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SD - 1) * OPT) : "memory");
+                    u32x4 (&nx)[2] = sx[(j + 1) % SD];
+                    asm volatile("" : "+v"(nx[0]), "+v"(nx[1]));
+                    if (t + 1 < t1) make_p(nx, t + 1, pn);                 // (VALU work under this tile's MFMAs; no tail masking:
                                                                            //  pass 1 stored P~ = 0 for keys past K)
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    if (ct < nct) {
-                        if (ct + PF < nct) issue_seg(ct + PF);
-                        // in flight behind column tile ct: min(PF, nct - 1 - ct) tiles of 4 reads
-                        const int ahead = (nct - 1 - ct) < PF ? (nct - 1 - ct) : PF;
+                    for (int ct = 0; ct < NCTC; ++ct) {
+                        if (ct + PF < NCTC) issue_seg(ct + PF);
+                        // in flight behind column tile ct: min(PF, NCTC - 1 - ct) tiles of 4 reads
+                        const int ahead = (NCTC - 1 - ct) < PF ? (NCTC - 1 - ct) : PF;
                         if (ahead >= 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                         else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1677,14 +1707,28 @@ __global__ __launch_bounds__(512, 1) void infonce_wide_pv2_kernel(const bf16_raw
                         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], __builtin_bit_cast(bf16x8, k1), o, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                }
+                };
+                sweep_cols(std::integral_constant<int, 8>{});
                 pa[0] = pn[0];
                 pa[1] = pn[1];
                 __builtin_amdgcn_s_barrier();                              // every wave is done with slot t
                 slot_cur = slot_cur == NB - 1 ? 0 : slot_cur + 1;
             }
-        }
+    };
+    // (the steps of one trip are NESTED behind each other's guards -- `break`, not three independent `if (t < t1)`: the audit
+    //  walks every path of the compiled code and cannot know that t + 1 >= t1 rules out t + 2 < t1)
+    static_assert(SD == 3, "three steps per trip");
+#pragma unroll 1
+    for (int tb = t0; tb < t1; tb += SD) {
+        tile_step(tb, std::integral_constant<int, 0>{});
+        if (tb + 1 >= t1) break;
+        tile_step(tb + 1, std::integral_constant<int, 1>{});
+        if (tb + 2 >= t1) break;
+        tile_step(tb + 2, std::integral_constant<int, 2>{});
     }
+    // the requests past the group's last tile have landed too: from here on their registers are free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 
     if (live) {
 #pragma unroll

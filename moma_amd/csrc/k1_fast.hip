@@ -1040,8 +1040,9 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
 #pragma unroll
             for (int jj = 0; jj < GP; ++jj) {
                 if (g0 + jj < TW) {
-                    const int t0 = tile_row0(g0 + jj);
-                    if constexpr (!ROLE_KV) {
+                    int t0 = tile_row0(g0 + jj);
+                    asm volatile("" : "+v"(t0));                 // (opaque per use: hipcc otherwise hoists the row offsets of every
+                    if constexpr (!ROLE_KV) {                    //  tile, segment and sweep out of the loops -- 64-bit pairs, spilled)
                         dma_tile32(vb, ld, t0, N, c0, nch, img1, lane);
                         dma_tile32(kb, ld, t0, N, c0, nch, img2, lane);
                     } else {
@@ -1087,7 +1088,11 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
                     }
                 }
                 dsa[j][0] = tile_as_a(ds, 0); dsa[j][1] = tile_as_a(ds, 1);
-                pa[j][0] = tile_as_a(p, 0); pa[j][1] = tile_as_a(p, 1);
+                asm volatile("" : "+v"(dsa[j][0]), "+v"(dsa[j][1]));         // (formed HERE: left to hipcc the P / dS of every tile sink
+                if constexpr (ROLE_KV) {                                     //  behind the last tile and the X / S tiles of all of them
+                    pa[j][0] = tile_as_a(p, 0); pa[j][1] = tile_as_a(p, 1);  //  stay alive: 43 / 158 spilled registers at 3 / 4 tiles)
+                    asm volatile("" : "+v"(pa[j][0]), "+v"(pa[j][1]));
+                }
             }
         }
     }
@@ -1105,7 +1110,8 @@ __device__ __forceinline__ void k1_core_bwd_wide_role(char* smem, const CoreBwdA
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
-            const int t0 = tile_row0(j);
+            int t0 = tile_row0(j);
+            asm volatile("" : "+v"(t0));
             char* img = WHICH == 1 ? img1 : img2;                 // dV reads dA_t; dQ reads K_t; dK reads Qs_t
             // (one tile per wave: the last segment's images of phase 1 are still in place -- until the first reduction of this
             //  role has used the waves' image slices for its partial sums: the dK sweep always fetches)

@@ -183,6 +183,8 @@ def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in ms.parameters())
     # a replaced queue: same shapes, another tensor -> the old capture is not used for it; after the warm-up a new one serves
     old_ptr = contrast.memory.data_ptr()
+    retired = [contrast.memory]             # (kept alive: a freed queue's block may be handed out again for a later one, and a queue
+    #                                          at a captured address IS served by that capture -- rightly, but not what is tested here)
     contrast.memory = torch.nn.functional.normalize(torch.randn(K, d, device=dev)).to(torch.bfloat16)
     assert contrast.memory.data_ptr() != old_ptr
     before = contrast.memory.clone()
@@ -196,7 +198,9 @@ def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
     assert torch.equal(contrast.memory[untouched], before[untouched]) and not torch.equal(contrast.memory[rows], before[rows])
     # a THIRD storage: the runner is at capacity (max_graphs = 2) -- the variant unused longest (the first queue's, which can never
     # match again) makes room instead of leaving every later variant eager for good
+    retired.append(contrast.memory)
     contrast.memory = torch.nn.functional.normalize(torch.randn(K, d, device=dev)).to(torch.bfloat16)
+    assert contrast.memory.data_ptr() not in [t.data_ptr() for t in retired]
     idx0 = contrast.index
     opt.trace.clear()
     train_distill_moma(4, [batch() for _ in range(7)], mods, crits, trainer, contrast, optimizer, opt)

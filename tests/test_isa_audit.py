@@ -1,0 +1,208 @@
+"""CPU tests of scripts/audit_isa.py -- the static hazard audit of the hand-scheduled kernels (inline-asm loads / LDS reads /
+stores / MFMAs against the compiler's blind spot for what an asm statement has in flight).
+
+  * the rules themselves on hand-written instruction streams (what is a hazard, what closes a window, which paths the walk may
+    rule out);
+  * the product: every kernel of csrc/infonce_fused.hip, infonce_f32.hip, k1_fast.hip is clean (one cross-compile, ~1 min);
+  * the two failures of round 5, rebuilt as source mutations and NOT run: the dropped `lgkmcnt` wait of the ablation build that
+    ended in an aperture violation, and the inline-asm write-through store that cost a parity test -- the audit flags both.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import audit_isa as A  # noqa: E402
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+needs_hipcc = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+
+
+def kernel(body: str) -> str:
+    return "_Z1kv:\n" + "\n".join("\t" + l.strip() if not l.strip().endswith(":") else l.strip() for l in body.strip().split("\n")) + "\n.Lfunc_end0:\n"
+
+
+def problems(body: str):
+    (ins, labels), = A.parse(kernel(body)).values()
+    return A.audit_function(ins, labels)[0]
+
+
+ASM = ";;#ASMSTART\n{}\n;;#ASMEND"
+
+
+def asm(*lines):
+    return ASM.format("\n".join(lines))
+
+
+def test_asm_load_needs_a_covering_wait():
+    # read before any wait
+    assert problems(asm("global_load_dwordx4 v[4:7], v[0:1], off") + "\nv_add_f32 v8, v4, v4\ns_endpgm")
+    # a wait that leaves one operation outstanding does not cover the youngest load
+    assert problems(asm("global_load_dwordx4 v[4:7], v[0:1], off", "s_waitcnt vmcnt(1)") + "\nv_add_f32 v8, v4, v4\ns_endpgm")
+    # ... but covers it once a younger vector-memory operation (an LDS-DMA piece, a store) has been issued behind it
+    assert not problems(asm("global_load_dwordx4 v[4:7], v[0:1], off") + "\nglobal_load_lds_dwordx4 v2, s[0:1]\n"
+                        + asm("s_waitcnt vmcnt(1)") + "\nv_add_f32 v8, v4, v4\ns_endpgm")
+    assert not problems(asm("global_load_dwordx4 v[4:7], v[0:1], off", "s_waitcnt vmcnt(0)") + "\nv_add_f32 v8, v4, v4\ns_endpgm")
+    # overwriting the destination while the load is in flight is as wrong as reading it
+    assert problems(asm("global_load_dwordx4 v[4:7], v[0:1], off") + "\nv_mov_b32 v5, 0\n" + asm("s_waitcnt vmcnt(0)") + "\ns_endpgm")
+    # a YOUNGER load into the same registers is ordered behind it (results return in issue order)
+    assert not problems(asm("global_load_dwordx4 v[4:7], v[0:1], off") + "\nglobal_load_dwordx4 v[4:7], v[2:3], off\n"
+                        "s_waitcnt vmcnt(0)\nv_add_f32 v8, v4, v4\ns_endpgm")
+    # a load the compiler emitted itself is the compiler's business
+    assert not problems("global_load_dwordx4 v[4:7], v[0:1], off\nv_add_f32 v8, v4, v4\ns_endpgm")
+
+
+def test_lds_reads_count_only_lds_operations():
+    rd = asm("ds_read_b128 v[4:7], v0", "ds_read_b128 v[8:11], v0 offset:16")
+    assert not problems(rd + "\n" + asm("s_waitcnt lgkmcnt(1)") + "\nv_add_f32 v12, v4, v4\ns_endpgm")
+    assert problems(rd + "\n" + asm("s_waitcnt lgkmcnt(1)") + "\nv_add_f32 v12, v8, v8\ns_endpgm")
+    # a scalar load shares the counter but returns out of order: it must not count as "younger"
+    assert problems(asm("ds_read_b128 v[4:7], v0") + "\ns_load_dword s4, s[0:1], 0x0\n" + asm("s_waitcnt lgkmcnt(1)")
+                    + "\nv_add_f32 v12, v4, v4\ns_endpgm")
+
+
+def test_windows_follow_every_path():
+    # the wait sits on one arm only
+    body = asm("global_load_dwordx4 v[4:7], v[0:1], off") + """
+        s_cmp_lt_i32 s4, 2
+        s_cbranch_scc1 .LBB0_2
+        """ + asm("s_waitcnt vmcnt(0)") + """
+        .LBB0_2:
+        v_add_f32 v8, v4, v4
+        s_endpgm"""
+    assert problems(body)
+    # a loop: the load at the bottom is consumed at the top of the next trip
+    loop = """
+        .LBB0_1:
+        v_add_f32 v8, v4, v4
+        """ + asm("global_load_dwordx4 v[4:7], v[0:1], off") + """
+        {}
+        s_cmp_lt_i32 s4, s5
+        s_cbranch_scc1 .LBB0_1
+        s_endpgm"""
+    assert problems(loop.format(""))
+    assert not problems(loop.format(asm("s_waitcnt vmcnt(0)")))
+
+
+def test_the_walk_rules_out_only_what_the_program_rules_out():
+    # request and wait under the SAME comparison of unchanged registers: the wait's count holds on every feasible path
+    body = asm("global_load_dwordx4 v[4:7], v[0:1], off") + """
+        s_cmp_lt_i32 s4, 2
+        s_cbranch_scc1 .LBB0_2
+        global_load_lds_dwordx4 v2, s[0:1]
+        .LBB0_2:
+        v_mov_b32 v9, 0
+        {clobber}
+        s_cmp_lt_i32 s4, 2
+        s_cbranch_scc1 .LBB0_4
+        """ + asm("s_waitcnt vmcnt(1)") + """
+        s_branch .LBB0_5
+        .LBB0_4:
+        """ + asm("s_waitcnt vmcnt(0)") + """
+        .LBB0_5:
+        v_add_f32 v8, v4, v4
+        s_endpgm"""
+    assert not problems(body.format(clobber=""))
+    # ... but not once the compared register has changed in between
+    assert problems(body.format(clobber="s_add_i32 s4, s4, 1"))
+    # hipcc refines a value step by step (`< 1`, `== 1`) and asks differently later (`< 2`): intervals connect the two
+    body = asm("global_load_dwordx4 v[4:7], v[0:1], off") + """
+        s_cmp_lt_i32 s4, 1
+        s_cbranch_scc1 .LBB0_3
+        global_load_lds_dwordx4 v2, s[0:1]
+        s_cmp_eq_u32 s4, 1
+        s_cbranch_scc1 .LBB0_3
+        global_load_lds_dwordx4 v2, s[2:3]
+        .LBB0_3:
+        s_cmp_gt_i32 s4, 1
+        s_cselect_b64 s[6:7], -1, 0
+        s_and_b64 vcc, exec, s[6:7]
+        s_cbranch_vccz .LBB0_4
+        """ + asm("s_waitcnt vmcnt(2)") + """
+        s_branch .LBB0_5
+        .LBB0_4:
+        """ + asm("s_waitcnt vmcnt({n})") + """
+        .LBB0_5:
+        v_add_f32 v8, v4, v4
+        s_endpgm"""
+    assert problems(body.format(n=1))          # the path with NO piece behind the load takes this wait too
+    assert not problems(body.format(n=0))
+    # the structuriser's flags: s_mov_b64 0 / -1 ... s_andn2_b64 vcc, exec, flag ... s_cbranch_vccnz
+    body = asm("global_load_dwordx4 v[4:7], v[0:1], off") + """
+        s_mov_b64 s[2:3], -1
+        s_and_b64 vcc, exec, s[8:9]
+        s_cbranch_vccz .LBB0_2
+        """ + asm("s_waitcnt vmcnt(0)") + """
+        s_mov_b64 s[2:3], 0
+        .LBB0_2:
+        s_andn2_b64 vcc, exec, s[2:3]
+        s_cbranch_vccnz .LBB0_4
+        """ + asm("s_waitcnt vmcnt(0)") + """
+        .LBB0_4:
+        v_add_f32 v8, v4, v4
+        s_endpgm"""
+    assert not problems(body)
+
+
+def test_store_data_hazard_window():
+    st = "global_store_dwordx4 v[0:1], v[4:7], off"
+    assert problems(asm(st) + "\nv_mov_b32 v4, 0\ns_endpgm")
+    assert problems(asm(st) + "\ns_nop 0\nv_mov_b32 v6, 0\ns_endpgm")
+    assert not problems(asm(st, "s_nop 1") + "\nv_mov_b32 v4, 0\ns_endpgm")
+    assert not problems(asm(st) + "\nv_mov_b32 v8, v4\nv_mov_b32 v9, v5\nv_mov_b32 v4, 0\ns_endpgm")     # reads do not matter
+    assert not problems(asm("global_store_dwordx2 v[0:1], v[4:5], off") + "\nv_mov_b32 v4, 0\ns_endpgm")    # <= 8 bytes: no hazard
+
+
+def test_mfma_result_window():
+    mf = "v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]"
+    assert problems(asm(mf) + "\nv_add_f32 v30, v0, v0\ns_endpgm")
+    assert problems(asm(mf, "s_nop 15") + "\nv_add_f32 v30, v0, v0\ns_endpgm")
+    assert not problems(asm(mf, "s_nop 15", "s_nop 3") + "\nv_add_f32 v30, v0, v0\ns_endpgm")
+    # the dependent accumulation chain is the hardware's business; a result as A / B operand is not
+    assert not problems(asm(mf, mf) + "\ns_endpgm")
+    assert problems(asm(mf, "v_mfma_f32_32x32x16_bf16 v[32:47], v[0:3], v[20:23], v[32:47]") + "\ns_endpgm")
+
+
+@needs_hipcc
+def test_product_kernels_are_clean():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "audit_isa.py"), "-q"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
+
+
+def _compile_mutation(args):
+    src, old, new, tmp, name = args
+    assert old in src, name
+    d = os.path.join(tmp, name)
+    os.makedirs(d)
+    with open(os.path.join(d, "infonce_fused.hip"), "w") as f:
+        f.write(src.replace(old, new))
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "moma_amd", "csrc"),
+                    "-I" + os.path.join(ROOT, "include"), "-save-temps", "-c", "infonce_fused.hip", "-o", "x.o"], cwd=d, check=True,
+                   capture_output=True)
+    return open(os.path.join(d, "infonce_fused-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+
+
+@needs_hipcc
+def test_round5_failures_are_flagged_statically():
+    """(1) gpurun_out/k2var/scoreburst.log (round 5): an ablation build without the score product's lgkmcnt wait died with
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  (2) commit 7789627: write-through partial stores as inline asm -- hipcc re-wrote
+    the data registers right behind the store and a parity test failed.  Neither build is run again: the audit sees both."""
+    src = open(os.path.join(ROOT, "moma_amd", "csrc", "infonce_fused.hip")).read()
+    store = "                dst[(c * 2 + g) * 64] = v;     // (non-temporal stores: same kernel time, +3 us on the combine that reads them back)\n"
+    asm_store = ("                { typedef unsigned u4 __attribute__((ext_vector_type(4))); const u4 vv = {v.x, v.y, v.z, v.w};\n"
+                 '                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + (c * 2 + g) * 64), "v"(vv) : "memory"); }\n')
+    with tempfile.TemporaryDirectory() as tmp:
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            nowait, wtstore = ex.map(_compile_mutation, [(src, "            wait_lgkm(ahead + pre);\n", "", tmp, "nowait"),
+                                                         (src, store, asm_store, tmp, "wtstore")])
+    for text, what in ((nowait, "covering lgkmcnt wait"), (wtstore, "store-data hazard window")):
+        flagged = {}
+        for name, (ins, labels) in A.parse(text).items():
+            if "infonce_flash_kernelILi512ELb1E" in name:
+                flagged[name] = [p for p in A.audit_function(ins, labels)[0] if what in p]
+        assert flagged and all(flagged.values()), (what, flagged)
