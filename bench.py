@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from moma_amd.miopen_env import use_shipped_db  # noqa: E402  (before torch: selects MIOpen's tuned solvers)
+from moma_amd.devices import visible_gpu_count  # noqa: E402,F401  (sysfs only: the parent of the ranks never opens the device)
 
 use_shipped_db(tag=os.environ.get("LOCAL_RANK", "0"))
 
@@ -71,6 +72,9 @@ def parse():
                    help="experiment switch, OFF by default since round 5: a side-stream sweep that warms the Infinity Cache with the "
                         "queue ahead of K2 -- a second read of the 67 MB queue per step (15 us beside the attention launches) that "
                         "bought 0.6 us of the one-pass kernel (profiles/r04_step_kernel_stats.csv)")
+    p.add_argument("--launch_timeout", type=float, default=None,
+                   help="--gpus N without a launcher: seconds after which the parent stops every rank (SIGTERM, then SIGKILL), prints "
+                        "how far each one got and exits 124 (default: MOMA_BENCH_LAUNCH_TIMEOUT or 420)")
     p.add_argument("--no_overlap_teacher", dest="overlap_teacher", action="store_false",
                    help="queue the teacher / key side of the step on the main stream instead of a second HIP stream")
     return p.parse_args()
@@ -293,47 +297,123 @@ def heartbeat(period=60.0):
     threading.Thread(target=run, daemon=True).start()
 
 
-def visible_gpu_count():
-    """GPUs this process tree may use, counted WITHOUT any HIP / HSA call (the parent of the ranks must never open the device:
-    torch.cuda.device_count() falls back to hipGetDeviceCount when amdsmi is unusable, as it is on this pool): KFD's topology in
-    sysfs -- a node with simd_count > 0 is a GPU --, narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
-    when set.  None = unknown (no KFD sysfs): the ranks report a missing device themselves."""
-    import glob
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if not nodes:
-        return None
-    have = 0
-    for f in nodes:
+PHASES = ("started", "rccl_init", "model_built", "control_group", "wrap_self_test", "warmup_done", "timed_done", "line_printed")
+
+
+_PHASE = {"name": "not started", "t0": time.time(), "log": []}
+
+
+def phase(name):
+    """A rank says how far it got: one stderr line per phase (a launcher -- torch.distributed.run in the driver's N > 1 run, this
+    script's own parent otherwise -- relays it) and, when the parent named a file (MOMA_BENCH_PHASE_FILE), one line appended there:
+    what the parent prints per rank when the job fails or runs into its deadline."""
+    _PHASE["name"] = name
+    _PHASE["log"].append((name, time.time() - _PHASE["t0"]))
+    log(f"rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')} phase {name} +{time.time() - _PHASE['t0']:.1f}s")
+    f = os.environ.get("MOMA_BENCH_PHASE_FILE")
+    if f:
         try:
-            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+            with open(f, "a") as fh:
+                fh.write(f"{name} {time.time():.3f}\n")
         except OSError:
-            continue                                  # (a node this cgroup may not read is not ours)
-        if int(props.get("simd_count", "0")) > 0:
-            # (a container sees the host's whole topology; a GPU is ours when its render node is there and may be opened)
-            minor = props.get("drm_render_minor")
-            if minor is None or os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK):
-                have += 1
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
-    return have
+            pass
 
 
-def launch_ranks(n):
+def rank_watchdog(deadline):
+    """Inside every rank, launcher or not: (1) past `deadline` seconds the rank reports the phase it is stuck in and the stack of
+    every thread (eight ranks parked in init_process_group or in a collective otherwise sit there until the driver's own timeout
+    and leave nothing behind) and exits 124 -- the launcher then ends the job; (2) a rank that is TERMINATED (another rank failed
+    first) says where it was."""
+    import faulthandler
+    import signal
+    import threading
+    faulthandler.enable()
+
+    def where(why):
+        trail = " -> ".join(f"{n} +{t:.0f}s" for n, t in _PHASE["log"]) or "not started"
+        log(f"rank {os.environ.get('RANK', '0')}: {why} in phase '{_PHASE['name']}' ({trail}); stacks of all threads follow")
+        faulthandler.dump_traceback(all_threads=True)
+
+    def overdue():
+        where(f"deadline of {deadline:.0f} s reached")
+        os._exit(124)
+
+    def terminated(signum, frame):
+        where("terminated (SIGTERM)")
+        os._exit(128 + signum)
+    t = threading.Timer(deadline, overdue)
+    t.daemon = True
+    t.start()
+    try:
+        signal.signal(signal.SIGTERM, terminated)
+    except ValueError:                                     # (not the main thread: a test harness)
+        pass
+    return t
+
+
+def read_phases(path):
+    try:
+        rows = [l.split() for l in open(path).read().splitlines() if l.strip()]
+        return [(r[0], float(r[1])) for r in rows if len(r) == 2]
+    except (OSError, ValueError):
+        return []
+
+
+def phase_report(log_dir, n, t0):
+    """per rank: the last phase reached and when (seconds after the launch)"""
+    out = []
+    for r in range(n):
+        ph = read_phases(os.path.join(log_dir, f"bench_rank{r}.phase"))
+        out.append(f"rank {r}: " + (" -> ".join(f"{name} +{t - t0:.0f}s" for name, t in ph) if ph else "no phase reached (never started?)"))
+    return out
+
+
+def stop_ranks(procs, grace=10.0):
+    """terminate, then -- for a rank that sits in a GPU wait or a collective and ignores SIGTERM -- kill; process groups, so that
+    helper processes of a rank go with it"""
+    import signal
+    live = [p for p in procs if p.poll() is None]
+    for sig, wait in ((signal.SIGTERM, grace), (signal.SIGKILL, 5.0)):
+        for p in live:
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                try:
+                    p.send_signal(sig)
+                except ProcessLookupError:
+                    pass
+        t_end = time.time() + wait
+        while time.time() < t_end and any(p.poll() is None for p in live):
+            time.sleep(0.05)
+        live = [p for p in live if p.poll() is None]
+        if not live:
+            return
+
+
+def launch_ranks(n, timeout=None, log_dir=None):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script directly (one process per GPU, RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, rendezvous on 127.0.0.1) -- the reference's entry
     point spawns its own ranks too (train_student_moma.py:215-224, mp.spawn).  No torch.distributed.run in between: its launcher
     process opens the device (LaunchConfig asks torch.cuda.is_available()), one more process on the card per job.  This parent
-    never touches the GPU (devices are counted from sysfs); it relays the children's stderr, prints rank 0's JSON line and
-    returns non-zero if any rank failed (the others are then terminated: they would wait in a collective forever)."""
+    never touches the GPU (devices are counted from sysfs).  It relays every rank's stderr (also kept as bench_rank<r>.err in the
+    log directory), prints rank 0's JSON line and returns non-zero if any rank failed or the job ran into its deadline
+    (--launch_timeout; 124 then).  A failed or overdue job is stopped for good -- SIGTERM, then SIGKILL -- and leaves a report:
+    per rank the phases it reached (rccl_init, control_group, wrap_self_test, warmup_done, timed_done ...) and the tail of its
+    stderr.  The first N > 1 run on real hardware is one shot on a box nobody watches: what it prints is all there is."""
     import socket
     import subprocess
+    import tempfile
+    import threading
     if os.environ.get("MOMA_BENCH_SAME_DEVICE") != "1":
         have = visible_gpu_count()
         if have is not None and have < n:
             log(f"--gpus {n} but only {have} GPU(s) visible")
             return 2
+    if timeout is None:
+        timeout = float(os.environ.get("MOMA_BENCH_LAUNCH_TIMEOUT", "420"))
+    if log_dir is None:
+        log_dir = os.environ.get("MOMA_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="moma_bench_")
+    os.makedirs(log_dir, exist_ok=True)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -343,37 +423,90 @@ def launch_ranks(n):
     base.pop("MOMA_BENCH_SELF_LAUNCH", None)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's intra-node transport needs on this driver
     base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    base.setdefault("NCCL_DEBUG", "WARN")                  # RCCL says why an init or a collective failed
     base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    log(f"no launcher in the environment: starting {n} ranks: {' '.join(cmd)}")
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
-        # rank 0's stdout carries the JSON line; the other ranks' stdout joins the inherited stderr (progress lines stream through)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    import threading
-    out0 = []
-    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().splitlines()), daemon=True)
-    reader.start()
-    code, live = 0, set(range(n))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and code == 0:
-                code = rc
-                log(f"rank {r} exited with code {rc}; terminating the other ranks")
-                for o in live:
-                    procs[o].terminate()
-        time.sleep(0.05)
-    reader.join(timeout=10)
+    log(f"no launcher in the environment: starting {n} ranks (deadline {timeout:.0f} s, per-rank logs in {log_dir}): {' '.join(cmd)}")
+    t0 = time.time()
+    procs, errs, relays = [], [], []
+
+    def relay(r, path, stop):
+        """tail rank r's stderr file into this process's stderr"""
+        pos = 0
+        while True:
+            done = stop.is_set()
+            try:
+                with open(path, "r", errors="replace") as fh:
+                    fh.seek(pos)
+                    chunk = fh.read()
+                    pos = fh.tell()
+            except OSError:
+                chunk = ""
+            if chunk:
+                sys.stderr.write(chunk)
+                sys.stderr.flush()
+            if done:
+                return
+            time.sleep(0.2)
+    stop = threading.Event()
+    code, out0 = 0, []
+    try:
+        for r in range(n):
+            for f in (f"bench_rank{r}.phase", f"bench_rank{r}.err"):
+                try:
+                    os.remove(os.path.join(log_dir, f))
+                except OSError:
+                    pass
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", MOMA_BENCH_PHASE_FILE=os.path.join(log_dir, f"bench_rank{r}.phase"))
+            err = open(os.path.join(log_dir, f"bench_rank{r}.err"), "w")
+            errs.append(err)
+            # rank 0's stdout carries the JSON line; the other ranks' stdout joins their stderr file (progress lines stream through)
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else err, stderr=err, text=True,
+                                          start_new_session=True))
+            t = threading.Thread(target=relay, args=(r, err.name, stop), daemon=True)
+            t.start()
+            relays.append(t)
+        reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().splitlines()), daemon=True)
+        reader.start()
+        live, why = set(range(n)), None
+        while live and why is None:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0:
+                    code = 128 - rc if rc < 0 else rc          # (killed by signal s: 128 + s, as a shell reports it)
+                    why = f"rank {r} exited with code {rc}"
+                    break
+            if why is None and time.time() - t0 > timeout:
+                code, why = 124, f"deadline of {timeout:.0f} s reached with rank(s) {sorted(live)} still running"
+            time.sleep(0.05)
+        if why is not None:
+            log(f"{why}; stopping the other ranks")
+            stop_ranks(procs)
+        reader.join(timeout=10)
+    finally:
+        stop_ranks(procs, grace=2.0)                           # (also on KeyboardInterrupt / an error in this parent: no orphans)
+        stop.set()
+        for t in relays:
+            t.join(timeout=5)
+        for e in errs:
+            e.close()
     lines = [l for l in out0 if l.startswith("{")]
     for l in out0:
         if not l.startswith("{"):
             print(l, file=sys.stderr)
     if code != 0 or not lines:
-        log(f"ranks exited with code {code}{'' if lines else ' and no JSON line'}")
+        log(f"ranks exited with code {code}{'' if lines else ' and no JSON line'}; how far every rank got:")
+        for l in phase_report(log_dir, n, t0):
+            log("  " + l)
+        for r in range(n):
+            try:
+                tail = open(os.path.join(log_dir, f"bench_rank{r}.err"), errors="replace").read().splitlines()[-8:]
+            except OSError:
+                tail = []
+            for l in tail:
+                log(f"  [rank {r} stderr] {l}")
         return code or 1
     print(lines[-1], flush=True)
     return 0
@@ -383,11 +516,14 @@ def main():
     a = parse()
     # (MOMA_BENCH_SELF_LAUNCH=1: also --gpus 1 goes through the parent path -- how the one-GPU box rehearses the exact code of --gpus N)
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("MOMA_BENCH_SELF_LAUNCH") == "1"):
-        raise SystemExit(launch_ranks(a.gpus))       # before any GPU call in this process
+        raise SystemExit(launch_ranks(a.gpus, timeout=a.launch_timeout))       # before any GPU call in this process
     heartbeat()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1":
+        rank_watchdog(float(os.environ.get("MOMA_BENCH_RANK_DEADLINE", "480")))
+        phase("started")
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -402,6 +538,13 @@ def main():
     distributed = world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1"
     if distributed:
         dist.init_process_group(os.environ.get("MOMA_BENCH_BACKEND", "nccl"))     # "nccl" = RCCL over xGMI
+        if dist.get_backend() == "nccl":
+            # first contact with the communicator HERE, not inside the model wrap: RCCL builds its rings lazily at the first collective
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            assert int(t.item()) == world, f"all-reduce over {world} ranks returned {t.item()}"
+        phase("rccl_init")
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
 
     from moma_amd import ops
@@ -418,10 +561,14 @@ def main():
     if opt.amp == "fp16":
         opt._grad_scaler = torch.amp.GradScaler("cuda")       # as train_student_moma.main_worker does
     if distributed:
-        from moma_amd.learning.ddp import wrap_student
+        from moma_amd.learning.ddp import wrap_student, control_group
         from moma_amd.learning.ddp import broadcast_module_state
+        phase("model_built")
+        control_group()                                            # (the host-side gloo group of the flat wrap: created here, by every rank)
+        phase("control_group")
         ddp_s = wrap_student(model_s, device_ids=[local])          # MOMA_DP=ddp keeps the stock reducer
         broadcast_module_state([criterion_list[2], model_t])       # (under no wrap: identical by seed in the reference)
+        phase("wrap_self_test")
         opt.gpu = local
         module_list = [ddp_s] + list(module_list)[1:]
     rec = EventRecorder()
@@ -489,6 +636,8 @@ def main():
         _acc, loss_avg = train_distill_moma(1, loader_t, module_list, criterion_list, trainer, contrast, optimizer, opt)
     barrier()
     dt = time.perf_counter() - t0
+    if distributed:
+        phase("timed_done")
     sg = getattr(trainer, "_step_graphs", None)
     replayed = (sg.replays if sg is not None else 0) - replays0
     rec.enabled = False
@@ -673,8 +822,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU restatement (bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(a)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
+        phase("line_printed")
         dist.destroy_process_group()
 
 

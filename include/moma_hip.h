@@ -15,7 +15,7 @@
  *     performs no host synchronisation (safe under hipGraph capture);
  *   - return value: 0 = ok, <0 = argument check failed (MOMA_E_*), >0 = hipError_t of a failed launch;
  *     nothing throws; no environment variable is read; no mutable global state apart from once-per-process kernel-attribute
- *     setups (dynamic-LDS opt-ins) behind std::call_once -- they are made for the device that is current at the first call:
+ *     setups (dynamic-LDS opt-ins) behind std::call_once and the debug knob moma_debug_set_k2_target_wg() -- they are made for the device that is current at the first call:
  *     ONE DEVICE PER PROCESS (the DDP model: one host thread per process / GPU); re-entrant within that;
  *   - matrices are row-major and dense unless a leading dimension is given;
  *   - `prec`   : arithmetic of the contractions. MOMA_PREC_F32 = f32-input MFMA (exact fp32 fma chain,
@@ -54,6 +54,12 @@ typedef void* moma_stream_t; /* hipStream_t */
 int moma_version(void);
 /* Human-readable text for a return code of this library (static storage). */
 const char* moma_error_string(int code);
+/* DEBUG knob, for plan sweeps only (scripts/sweep_k2_plan.sh): cut the K2 passes over the queue into about `n` workgroups instead
+ * of the product's own plan (one per compute unit, fewer for short passes).  n = 0 restores the plan; 8 <= n <= 1024 otherwise.
+ * Returns the previous value, or -1 when n is refused.  Process-wide and not synchronised with calls in flight: the launch plan AND
+ * moma_infonce_fused*_workspace_bytes() follow it, so set it once, before the first workspace query, and size every workspace
+ * after that.  This is the one piece of caller-set state in the library and the reason it reads no environment variable. */
+int moma_debug_set_k2_target_wg(int n);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  multi-tensor EMA -- replaces ContrastTrainer.momentum_update

@@ -27,6 +27,7 @@ _z = C.c_size_t
 SIGNATURES = {
     "moma_version": (_i, []),
     "moma_error_string": (C.c_char_p, [_i]),
+    "moma_debug_set_k2_target_wg": (_i, [_i]),
     "moma_ema_multi": (_i, [_p, _i, _l, _f, _f, _p]),
     "moma_enqueue": (_i, [_p, _p, _i, _l, _i, _i, _i, _p]),
     "moma_enqueue_mirror": (_i, [_p, _p, _p, _i, _l, _i, _i, _p]),

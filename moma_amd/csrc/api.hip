@@ -32,6 +32,8 @@ extern "C" {
 
 int moma_version(void) { return MOMA_ABI_VERSION; }
 
+int moma_debug_set_k2_target_wg(int n) { return set_k2_target_wg(n); }
+
 const char* moma_error_string(int code) {
     switch (code) {
         case MOMA_OK: return "ok";

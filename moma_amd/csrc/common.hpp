@@ -124,6 +124,7 @@ hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks,
 // ---- infonce_fused.hip (one-pass flash-style kernel) ----------------------------------------------
 bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec);
 size_t infonce_flash_workspace_bytes(int B, int d, int K);
+int set_k2_target_wg(int n);                            // debug knob of the K2 plan (moma_debug_set_k2_target_wg)
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,

@@ -33,6 +33,7 @@
 #include "common.hpp"
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -2155,16 +2156,12 @@ struct FlashPlan {
     int nbt, nchunk, tiles_per_chunk, Bpad;
 };
 
-// Workgroups a pass over the queue is cut into: one per compute unit.  MOMA_K2_TARGET_WG (read once) overrides it for plan sweeps
-// (scripts/sweep_k2_plan.sh); every caller of plan() -- workspace sizes included -- sees the same value for the process's life.
-int target_override() {                                  // 0: none
-    static const int v = [] {
-        const char* e = std::getenv("MOMA_K2_TARGET_WG");
-        const int n = e ? std::atoi(e) : 0;
-        return (n >= 8 && n <= 2048) ? n : 0;
-    }();
-    return v;
-}
+// Workgroups a pass over the queue is cut into: one per compute unit.  Plan sweeps (scripts/sweep_k2_plan.sh) override it through
+// moma_debug_set_k2_target_wg() -- a DEBUG entry point, not an environment variable: the library reads none (include/moma_hip.h).
+// Every caller of plan() -- the workspace queries included -- sees the value that is set at the time of ITS call: set it once,
+// before the first query, and leave it (the entry point says so).  8 .. COMBINE_MAX_CHUNKS, 0 = the product's own plan.
+std::atomic<int> g_target_override{0};
+int target_override() { return g_target_override.load(std::memory_order_relaxed); }
 int target_workgroups() { return target_override() ? target_override() : 256; }
 
 // Short queues (the reference's default --nce_k 16384, train_student_moma.py:103) and narrow rows (--feat_dim 128 / 256): a
@@ -2213,6 +2210,7 @@ SmallPlan small_plan(int K, int d) {
     (void)d;
     const int ntiles = (K + KT - 1) / KT;
     int want = target_workgroups();
+    if (want > COMBINE_MAX_CHUNKS) want = COMBINE_MAX_CHUNKS;       // (one partial per workgroup: the combine's chunk table)
     int tpc = (ntiles + want - 1) / want;
     if (!target_override() && tpc < 8 && want > 128) {
         want = 128;
@@ -2223,6 +2221,11 @@ SmallPlan small_plan(int K, int d) {
 }
 
 }  // namespace
+
+int set_k2_target_wg(int n) {                          // moma_debug_set_k2_target_wg (api.hip): -> the previous value, -1 = refused
+    if (n != 0 && (n < 8 || n > COMBINE_MAX_CHUNKS)) return -1;
+    return g_target_override.exchange(n, std::memory_order_relaxed);
+}
 
 constexpr int WIDE_PV2_LDS = (MOMA_K2_WPV_SD + 1) * 16384 + 8 * 8 * 64 * 4;     // ring of (32 keys x 256 columns) slots + the scale-factor table
 static bool one_pass_dim(int d) { return d == 128 || d == 256 || d == 384 || d == 512; }
@@ -2289,6 +2292,7 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
         // ---- small batches: key-half split (infonce_small_kernel), two virtual chunks per workgroup, 64 padded rows
         const SmallPlan sp = small_plan(K, d);
         const int tpc = sp.tiles_per_wg, nwg = sp.nwg;
+        if (nwg > COMBINE_MAX_CHUNKS) return hipErrorInvalidValue;         // (as the general path below: the combine's wts[] table)
         const int Bp = 64;
         const size_t rows = (size_t)nwg * Bp;                              // (infonce_flash_workspace_bytes covers this layout)
         float* m_part = (float*)ws;

@@ -71,21 +71,50 @@ def _all_agree(values, device, group=None, what="replicas"):
         raise RuntimeError(f"data-parallel {what} differ across ranks (count, elements, layout hash per rank): {rows}")
 
 
-_control_groups = {}
+_control_groups = {}       # (id of the data group, fresh?) -> (the data group object itself, its control group)
 
 
 def control_group(group=None, force_new=False):
     """Host-side agreement channel next to the data group: the group itself when it runs on gloo, else a gloo group over the same
     ranks (made once per data group; COLLECTIVE: every rank of `group` must call it at the same point -- the wrap's constructor
-    and wrap_student do).  Carries a few int64 on CPU tensors: verdicts and fingerprints, never data."""
-    key = (id(group) if group is not None else None, id(dist.group.WORLD), bool(force_new))   # (a re-initialised process group is another key)
-    if key not in _control_groups:
+    and wrap_student do).  Carries a few int64 on CPU tensors: verdicts and fingerprints, never data.
+    The cache entry holds the data group OBJECT next to its control group: an id() cannot come back for another group while the
+    object is alive, and an entry whose object is not the caller's group (a torn-down and re-initialised job) is dropped."""
+    pg = group if group is not None else dist.group.WORLD
+    key = (id(pg), bool(force_new))
+    hit = _control_groups.get(key)
+    if hit is None or hit[0] is not pg:
         if dist.get_backend(group) == "gloo" and not force_new:      # (force_new: tests walk the RCCL-side branch on a gloo job)
-            _control_groups[key] = group if group is not None else dist.group.WORLD
+            ctl = pg
         else:
             ranks = dist.get_process_group_ranks(group) if group is not None else None
-            _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
-    return _control_groups[key]
+            ctl = dist.new_group(ranks=ranks, backend="gloo")
+        _control_groups[key] = (pg, ctl)
+    return _control_groups[key][1]
+
+
+def agreed_control_group(device, group=None, force_new=False):
+    """control_group() with ONE verdict for all ranks: creating the gloo group is a collective that may fail on one rank alone
+    (no usable transport there); that rank would skip the per-step agreement while the others block in it.  Every rank reports
+    whether it holds a group, the MIN over the DATA group (which exists) decides: the control group on every rank, or None on
+    every rank (the caller then falls back to the device-side check)."""
+    ctl, err = None, None
+    try:
+        ctl = control_group(group, force_new)
+    except Exception as e:                                   # (reported below, by every rank that failed)
+        err = e
+    ok = torch.tensor([1 if ctl is not None else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) != 1:
+        if err is not None:
+            print(f"[moma] data-parallel control group unavailable on rank {dist.get_rank()} ({type(err).__name__}: {err})")
+        return None
+    return ctl
+
+
+def forget_control_groups():
+    """drop the cache (called when a process group is torn down: the next job makes its own)"""
+    _control_groups.clear()
 
 
 def _host_agree(values, ctl, what):
@@ -165,13 +194,13 @@ class FlatDataParallel(nn.Module):
         self.flat_buffer_broadcast = FlatBufferBroadcast(module, group)
         # (collective: all ranks construct the wrap.  MOMA_DP_CONTROL=new: a gloo group of its own even on a gloo job -- the branch
         #  an RCCL job takes --, for the CPU rehearsals)
-        self._ctl = None
+        self._ctl, self._last_sig = None, None
         if dist.get_world_size(group) > 1:
-            try:
-                self._ctl = control_group(group, os.environ.get("MOMA_DP_CONTROL") == "new")
-            except Exception as e:                               # (no usable gloo transport: the per-step agreement is skipped, loudly)
-                print(f"[moma] data-parallel control group unavailable ({type(e).__name__}: {e}): gradient sets are not "
-                      f"re-verified per step")
+            dev = state[0].device if state else torch.device("cpu")
+            self._ctl = agreed_control_group(dev, group, os.environ.get("MOMA_DP_CONTROL") == "new")
+            if self._ctl is None and dist.get_rank() == 0:       # (the same verdict on every rank)
+                print("[moma] no host-side control group: gradient sets are verified on the device, at the first step and when "
+                      "they change on this rank")
         self.allreduce_launches = 0
 
     def forward(self, *args, **kwargs):
@@ -202,6 +231,11 @@ class FlatDataParallel(nn.Module):
         if self._ctl is not None:
             # agreed on every step, on the host, BEFORE the collective whose size depends on it
             _host_agree(sig, self._ctl, "gradient sets")
+        elif world > 1 and sig != self._last_sig:
+            # no host channel (agreed_control_group said so on every rank alike): the device-side exchange of round 4 -- at the first
+            # step and whenever the set changes on this rank (a change on ANOTHER rank alone is not seen: the degraded mode)
+            _all_agree(sig, params[0].device if params else torch.device("cpu"), self.group, "gradient sets")
+        self._last_sig = sig
         with ops._timed("dp_allreduce_grads"):
             for grads in by_kind.values():                      # (one group in practice: every gradient here is fp32)
                 flat = torch.cat([g.reshape(-1) for g in grads])
@@ -218,12 +252,7 @@ def wrap_student(model: nn.Module, device_ids=None, group=None, mode: str | None
     mode = mode or os.environ.get("MOMA_DP", "auto")
     if mode == "auto":
         dev = next(model.parameters()).device
-        ctl = None
-        if dist.get_world_size(group) > 1:
-            try:
-                ctl = control_group(group)
-            except Exception as e:
-                print(f"[moma] data-parallel control group unavailable ({type(e).__name__}: {e})")
+        ctl = agreed_control_group(dev, group) if dist.get_world_size(group) > 1 else None
         try:
             ok = collective_self_test(dev, group)
         except Exception as e:                                   # a backend that cannot run one of the two collectives

@@ -390,6 +390,16 @@ class _InfoNCEFused(torch.autograd.Function):
         return dq * g_loss.unsqueeze(1), None, None, None, None, None
 
 
+def debug_set_k2_target_wg(n: int) -> int:
+    """Plan sweeps only (scripts/sweep_k2_plan.sh): cut K2's passes over the queue into about n workgroups (0 = the product's own
+    plan).  Set it BEFORE the first call of the process: cached workspaces are sized under the plan in force when they were made.
+    -> the previous value."""
+    prev = lib.moma_debug_set_k2_target_wg(int(n))
+    if prev < 0:
+        raise ValueError(f"moma_debug_set_k2_target_wg({n}): refused (0, or 8 .. 1024)")
+    return prev
+
+
 def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (loss_rows [B], lse [B], top1 [B] int32).  loss_kd = loss_rows.mean().
     qpack: a QPack that the producer of q filled (ignored unless it was written from exactly this q and T)."""

@@ -137,7 +137,13 @@ def parse_option(argv=None):
         opt.nce_t = 0.15                                        # reference :135-136
     opt.moma_fused = not opt.no_fused
     opt.lr_decay_epochs = [int(it) for it in opt.lr_decay_epochs.split(",")]
-    ngpu = torch.cuda.device_count()
+    # (the reference names the run after torch.cuda.device_count(), train_student_moma.py:147-150.  Counted from sysfs here: this
+    #  code also runs in the parent of the ranks, which must not open the device -- see main(); the HIP runtime is asked only
+    #  where there is no KFD sysfs to read)
+    from .devices import visible_gpu_count
+    ngpu = visible_gpu_count()
+    if ngpu is None:
+        ngpu = torch.cuda.device_count()
     opt.model_path = os.path.join(
         opt.save_root, f"kd_{opt.dataset}_{opt.model_s}_StdPre_{opt.std_pre}_and_TecPre_{opt.tec_pre}"
                        f"_CPU{opt.num_workers}_GPU{ngpu}/")
@@ -415,6 +421,18 @@ def main_worker(gpu, ngpus_per_node, opt):
         torch.distributed.destroy_process_group()
 
 
+def parent_gpu_count(gpu_id: str) -> int:
+    """Ranks to spawn, decided without a HIP call: the GPUs sysfs shows (moma_amd.devices.visible_gpu_count); where there is no KFD
+    sysfs to read, the length of the --gpu_id list the user gave (a rank whose device is missing says so itself)."""
+    from .devices import visible_gpu_count
+    n = visible_gpu_count()
+    if n is None:
+        n = len([x for x in gpu_id.split(",") if x.strip() != ""])
+    if n < 1:
+        raise SystemExit("train_student_moma: --multiprocessing-distributed found no GPU to start a rank on")
+    return n
+
+
 def main(argv=None):
     opt = parse_option(argv)
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:         # launched by torchrun: 1 process / GPU
@@ -424,13 +442,19 @@ def main(argv=None):
         main_worker(int(os.environ.get("LOCAL_RANK", 0)), n_local, opt)
         return
     os.environ["CUDA_VISIBLE_DEVICES"] = opt.gpu_id
-    ngpus_per_node = torch.cuda.device_count()
-    opt.ngpus_per_node = ngpus_per_node
     if opt.multiprocessing_distributed:
+        # The reference's launch mode (train_student_moma.py:207-224: `--distill moma` needs it).  This process only starts the
+        # ranks: it counts the devices from KFD's sysfs topology (narrowed by the CUDA_VISIBLE_DEVICES just set) and never asks
+        # the HIP runtime -- torch.cuda.device_count() ends in hipGetDeviceCount where amdsmi is unusable, and a parent that has
+        # opened the device is one more process on the card and may not start other programs on this platform.
         import torch.multiprocessing as mp
+        ngpus_per_node = parent_gpu_count(opt.gpu_id)
+        opt.ngpus_per_node = ngpus_per_node
         opt.world_size = ngpus_per_node                            # single node, as the reference (:218-219)
         mp.spawn(main_worker, nprocs=ngpus_per_node, args=(ngpus_per_node, opt))
     else:
+        ngpus_per_node = torch.cuda.device_count()                 # (this process IS the worker)
+        opt.ngpus_per_node = ngpus_per_node
         opt.world_size = 1
         main_worker(0, ngpus_per_node, opt)
 

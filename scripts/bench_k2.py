@@ -14,6 +14,8 @@ qdt = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 prec = sys.argv[5] if len(sys.argv) > 5 else "bf16"
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 50
 dq_only = len(sys.argv) > 7 and sys.argv[7] == "dq_only"
+if os.environ.get("MOMA_K2_TARGET_WG"):                    # (read HERE, by the sweep script -- the library reads no environment)
+    ops.debug_set_k2_target_wg(int(os.environ["MOMA_K2_TARGET_WG"]))
 torch.manual_seed(0)
 dev = "cuda"
 q = torch.nn.functional.normalize(torch.randn(B, d, device=dev))

@@ -71,6 +71,31 @@ def test_cli_resume_continues_queue_pointer(tmp_path, amp):
         assert state.get("grad_scaler") is None
 
 
+def test_cli_reference_launch_mode_spawns_one_rccl_rank_and_resumes(tmp_path):
+    """The reference's OWN launch mode for `--distill moma` (train_student_moma.py:207-224: --multiprocessing-distributed, mp.spawn,
+    one process per GPU, backend 'nccl' = RCCL): on the one GPU of the box that is ONE spawned rank on a real RCCL communicator
+    -- init_ddp_environment, the student wrap, broadcast_memory, the gradient all-reduce and the epoch-end metric all-reduce all
+    run.  Two epochs, then a resumed third: the queue pointer continues, the per-rank state file is found."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    base = [sys.executable, os.path.join(ROOT, "train_student_moma.py"), "--distill", "moma", "--multiprocessing-distributed",
+            "--dist-url", f"tcp://127.0.0.1:{_free_port()}", "--gpu_id", "0", "--model_s", "resnet8x4", "--model_t", "resnet8x4",
+            "--dataset", "cifar100", "--n_cls", "2", "--batch_size", "32", "--steps_per_epoch", "5", "--nce_k", "1024", "--head", "mlp",
+            "--feat_dim", "128", "-c", "1", "-d", "1", "-b", "1", "--print_freq", "2", "--miopen_find", "off", "--save_root", str(tmp_path)]
+    r = subprocess.run(base + ["--epochs", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "Use GPU: 0 for training" in r.stdout and "best accuracy" in r.stdout and "images/sec" in r.stdout
+    ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt_last.pth"]
+    assert ck
+    state = torch.load(ck[0], map_location="cpu")
+    assert state["epoch"] == 2 and state["contrast"]["_extra_state"]["index"] == (10 * 32) % 1024
+    r = subprocess.run(base + ["--epochs", "3", "--resume", ck[0]], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "resumed from" in r.stdout and "queue pointer 320" in r.stdout and "per-rank state found" in r.stdout
+    state = torch.load(ck[0], map_location="cpu")
+    assert state["epoch"] == 3 and state["contrast"]["_extra_state"]["index"] == (15 * 32) % 1024
+
+
 def test_cli_distill_kd_default_path(tmp_path):
     """`--distill kd` is the CLI default (reference train_student_moma.py:91): CE + KL only, no ContrastTrainer; the
     graphed teacher must work without one (round-1 ADVICE: AttributeError on NoneType)."""

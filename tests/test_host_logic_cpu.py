@@ -3,10 +3,14 @@ heads of CMO (all four kinds, reference state-dict keys), macro-F1, the bounded 
 import argparse
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _opt(**kw):
@@ -133,9 +137,12 @@ def _launch_with_children(monkeypatch, n, child_code, argv=("--gpus", "2")):
     monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
     real, seen = subprocess.Popen, []
 
+    _launch_with_children.procs = []
+
     def popen(cmd, **kw):
         seen.append((cmd, kw["env"]))
-        return real([sys.executable, "-c", child_code], **kw)
+        _launch_with_children.procs.append(real([sys.executable, "-c", child_code], **kw))
+        return _launch_with_children.procs[-1]
     monkeypatch.setattr(subprocess, "Popen", popen)
     rc = bench.launch_ranks(n)
     assert not torch.cuda.is_initialized()
@@ -172,6 +179,92 @@ def test_launch_ranks_a_failed_rank_ends_the_job(monkeypatch, capfd):
     rc, _ = _launch_with_children(monkeypatch, 2, code)
     assert rc == 5 and time.time() - t0 < 60
     assert "rank 1 exited with code 5" in capfd.readouterr().err
+
+
+def test_launch_ranks_deadline_stops_stuck_ranks_and_says_how_far_they_got(monkeypatch, capfd, tmp_path):
+    """eight ranks parked in init_process_group (or a collective) must not sit there until the
+    driver's own timeout and leave nothing.  Past --launch_timeout the parent stops every rank -- SIGTERM, then SIGKILL for one
+    that ignores it --, exits 124 and prints, per rank, the phases it reached and the tail of its stderr (also kept as
+    bench_rank<r>.err)."""
+    import time
+    code = ("import os, sys, time, signal\n"
+            "r = os.environ['RANK']\n"
+            "open(os.environ['MOMA_BENCH_PHASE_FILE'], 'a').write('started %f\\n' % time.time())\n"
+            "if r == '1':\n"
+            "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"            # a rank stuck where SIGTERM does not reach
+            "    open(os.environ['MOMA_BENCH_PHASE_FILE'], 'a').write('rccl_init %f\\n' % time.time())\n"
+            "print('rank', r, 'waiting in a collective', file=sys.stderr, flush=True)\n"
+            "time.sleep(600)\n")
+    monkeypatch.setenv("MOMA_BENCH_LOG_DIR", str(tmp_path))
+    monkeypatch.setenv("MOMA_BENCH_LAUNCH_TIMEOUT", "3")
+    t0 = time.time()
+    rc, seen = _launch_with_children(monkeypatch, 2, code)
+    took = time.time() - t0
+    err = capfd.readouterr().err
+    assert rc == 124 and took < 40, (rc, took)
+    assert "deadline of 3 s reached" in err and "rank 0: started" in err and "rank 1: started" in err and "-> rccl_init" in err
+    assert "[rank 1 stderr] rank 1 waiting in a collective" in err
+    assert all(env["NCCL_DEBUG"] == "WARN" and env["MOMA_BENCH_PHASE_FILE"].endswith(f"bench_rank{r}.phase") for r, (_, env) in enumerate(seen))
+    assert "waiting in a collective" in (tmp_path / "bench_rank0.err").read_text()
+    # nothing left behind: both children are gone (the SIGTERM-deaf one was killed)
+    assert all(p.poll() is not None for p in _launch_with_children.procs)
+    assert _launch_with_children.procs[1].returncode == -9
+
+
+def test_launch_ranks_reports_the_phases_when_a_rank_fails(monkeypatch, capfd, tmp_path):
+    code = ("import os, sys, time\n"
+            "f = os.environ['MOMA_BENCH_PHASE_FILE']\n"
+            "open(f, 'a').write('started %f\\nrccl_init %f\\n' % (time.time(), time.time()))\n"
+            "if os.environ['RANK'] == '0':\n"
+            "    open(f, 'a').write('wrap_self_test %f\\n' % time.time()); print('RuntimeError: self-test', file=sys.stderr); sys.exit(7)\n"
+            "time.sleep(600)\n")
+    monkeypatch.setenv("MOMA_BENCH_LOG_DIR", str(tmp_path))
+    rc, _ = _launch_with_children(monkeypatch, 2, code)
+    err = capfd.readouterr().err
+    assert rc == 7 and "rank 0 exited with code 7" in err
+    assert "rank 0: started" in err and "-> wrap_self_test" in err and "rank 1: started" in err and "[rank 0 stderr] RuntimeError: self-test" in err
+
+
+def test_rank_watchdog_reports_phase_and_stacks_then_exits_124():
+    """Inside a rank (so also under torch.distributed.run, how the driver starts its N > 1 runs): past its deadline a stuck rank
+    says which phase it is in, dumps the stacks of its threads and exits 124."""
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "bench.rank_watchdog(1.0); bench.phase('started'); bench.phase('rccl_init'); time.sleep(60)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, RANK="3", WORLD_SIZE="8"))
+    assert r.returncode == 124, r.stderr[-2000:]
+    assert "rank 3/8 phase rccl_init" in r.stderr and "rank 3: deadline of 1 s reached in phase 'rccl_init'" in r.stderr
+    assert "started +0s -> rccl_init +0s" in r.stderr and "most recent call first" in r.stderr
+
+
+def test_cli_parent_of_the_ranks_makes_no_hip_call(monkeypatch):
+    """`train_student_moma.py --multiprocessing-distributed` (the reference's launch mode, train_student_moma.py:207-224): the
+    process in front of mp.spawn counts devices from sysfs and never asks the HIP runtime (VERDICT r5 missing #2: it called
+    torch.cuda.device_count(), which ends in hipGetDeviceCount on this platform)."""
+    import torch.multiprocessing as mp
+    import moma_amd.devices as devices
+    import moma_amd.train_student_moma as tsm
+
+    def refuse(*a, **k):
+        raise AssertionError("the parent of the ranks asked the HIP runtime for devices")
+    monkeypatch.setattr(torch._C, "_cuda_getDeviceCount", refuse)
+    monkeypatch.setattr(torch.cuda, "device_count", refuse)
+    monkeypatch.setattr(torch.cuda, "is_available", refuse)
+    monkeypatch.setattr(devices, "visible_gpu_count", lambda: 3)
+    spawned = []
+    monkeypatch.setattr(mp, "spawn", lambda fn, nprocs, args: spawned.append((fn, nprocs, args)))
+    tsm.main(["--distill", "moma", "--multiprocessing-distributed", "--gpu_id", "0,1,2", "--model_s", "resnet8x4", "--model_t", "resnet8x4"])
+    (fn, nprocs, (ngpus, opt)), = spawned
+    assert fn is tsm.main_worker and nprocs == ngpus == opt.world_size == 3
+    assert os.environ["CUDA_VISIBLE_DEVICES"] == "0,1,2" and not torch.cuda.is_initialized()
+    # no KFD sysfs to read: the length of the user's --gpu_id list
+    monkeypatch.setattr(devices, "visible_gpu_count", lambda: None)
+    assert tsm.parent_gpu_count("0,1") == 2
+    monkeypatch.setattr(devices, "visible_gpu_count", lambda: 0)
+    with pytest.raises(SystemExit):
+        tsm.parent_gpu_count("0")
 
 
 def test_launch_ranks_refuses_more_ranks_than_gpus(monkeypatch):
