@@ -285,6 +285,35 @@ def cpu_baseline(a):
                       f"({dt:.1f} s)"}
 
 
+def cpu_baseline_c1(max_seconds=10.0, max_steps=60):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- beside the C2 sample: resnet8x4 student,
+    resnet32x4 teacher (frozen: another architecture cannot be an EMA of the student), CIFAR-shaped 32 x 32 batches of
+    8, 100 classes, `--head None` (d = s_dim = 256), K = 65536, `-c 1 -d 1 -b 1`; the step oracle (the reference's op order in
+    plain fp32 torch ops), bounded by time."""
+    from oracle.step_oracle import OracleCMO, OracleMoCo, StepOracle
+    from moma_amd.backbones import model_dict
+    cores = min(host_cores(), 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(12345)
+    B, n_cls, K, d = 8, 100, 65536, 256
+    ms, mt = model_dict["resnet8x4"](num_classes=n_cls), model_dict["resnet32x4"](num_classes=n_cls)
+    run = StepOracle(ms, mt, OracleCMO("None", d, d, d), OracleMoCo(d, K, 0.15), head="None", ema=False)
+    g = torch.Generator().manual_seed(12345)
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    y = torch.randint(0, n_cls, (B,), generator=g)
+    run.start_epoch()
+    for _ in range(2):
+        run.step(x, y)                               # warm-up (allocator, thread pool)
+    t0, n = time.time(), 0
+    while n < max_steps and time.time() - t0 < max_seconds:
+        run.step(x, y)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/step_oracle.py (reference op order, fp32), BASELINE configs[0]: resnet8x4 <- resnet32x4 (frozen), "
+                      f"32px, B={B}, n_cls={n_cls}, K={K}, d={d} (--head None), {n} timed steps after 2 warm-up ({dt:.1f} s)"}
+
+
 def heartbeat(period=60.0):
     """Progress line on stderr every minute (MIOpen's first-step kernel compilation can be silent for minutes)."""
     import threading
@@ -822,6 +851,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             log("timing the CPU restatement (bounded sample) ...")
             out["cpu_baseline"] = cpu_baseline(a)
+            out["cpu_baseline_c1"] = cpu_baseline_c1()
         print(json.dumps(out), flush=True)
     if distributed:
         phase("line_printed")

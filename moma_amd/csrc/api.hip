@@ -190,9 +190,12 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
         if (misaligned(queue, 16)) return MOMA_E_ALIGN;
         float* wide = (float*)workspace;
         void* ws2 = (char*)workspace + align_up((size_t)K * d * sizeof(float), 256);
+        // (the measurement span opens IN FRONT of the widening pass: 64 MB read + 128 MB written per call at the bench shape belong
+        //  to what this policy costs -- ADVICE r5)
+        if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, st);
         MOMA_TRY(launch_widen_bf16(queue, wide, (size_t)K * d, st));
         const int rc = hip_rc(launch_infonce_f32_flash(q, k, wide, B, d, K, inv_T, loss_rows, lse, top1, dq, ws2, st,
-                                                       (hipEvent_t)ev_begin, (hipEvent_t)ev_end));
+                                                       (hipEvent_t) nullptr, (hipEvent_t)ev_end));
         if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
         return rc;
     }

@@ -71,10 +71,10 @@ class PermFeed:
         j = self.i % self.SLOTS
         self.i += 1
         if self.done[j] is not None:
-            self.done[j].synchronize()                   # (four steps back: long done)
+            self.done[j].synchronize()                   # (four steps back: long done -- the loop's own pacing keeps three queued)
         torch.randperm(self.n, out=self.pinned[j])
         self.static.copy_(self.pinned[j], non_blocking=True)
-        ev = torch.cuda.Event(blocking=True)      # (a host that has run four steps ahead SLEEPS in synchronize() instead of spinning)
+        ev = torch.cuda.Event(blocking=True)      # (never waited on in practice, see above; a blocking-sync event SPINS on this runtime too)
         ev.record()
         self.done[j] = ev
 
@@ -168,9 +168,10 @@ class StepGraphs:
         platform every host-side wait of the runtime is a spin: hipEventSynchronize with a blocking-sync event, hipStreamSynchronize
         and the launch path all burn wall time = CPU time (scripts/diag_blocking_event.py; ROC_ACTIVE_WAIT_TIMEOUT=0 changes nothing)
         -- a full core per rank, eight of them on a node (round 4's driver line: 44.5 ms of CPU time in a 39.8 ms step).
-        So the loop paces itself: before issuing step k it waits until step k-2 has finished by POLLING its event between short
-        sleeps.  Two steps stay queued (the one executing and the next): the GPU never runs dry, the launches find room, and the
-        host's CPU time per step is what issuing costs."""
+        So the loop paces itself: before issuing step k it waits, by POLLING an event between short sleeps, for the event it
+        recorded when it STARTED issuing step k-2 -- i.e. for the end of step k-3 (the event sits behind everything issued for the
+        step before).  Steps k-2 and k-1 may still be in flight while k is issued: THREE steps queued at most (PermFeed's four
+        slots cover that): the GPU never runs dry, the launches find room, and the host's CPU time per step is what issuing costs."""
         evs = self.__dict__.setdefault("_step_done", [])
         if len(evs) >= 2:
             ev = evs.pop(0)

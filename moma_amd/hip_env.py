@@ -24,7 +24,7 @@ def configure() -> bool:
     every rank the CLI spawns (train_student_moma.py --multiprocessing-distributed, bench.py --gpus N) inherits it from here."""
     os.environ.setdefault(SWITCH, "0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # room for the kernel arguments of two queued steps (~2400 launches each): with the runtime's default pool the host hits the
+    # room for the kernel arguments of the queued steps (up to three, ~2400 launches each: helper/step_graph.py:_throttle): with the runtime's default pool the host hits the
     # end of it inside hipGraphLaunch every other step and spins there (bench: host issue alternating 25 / 47 ms per 40 ms step)
     os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(64 << 20))
     return os.environ[SWITCH] == "0"
