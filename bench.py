@@ -566,7 +566,12 @@ def main():
     # DDP reducer, hook-launched criterion all-reduce next to the captured teacher graphs -- with a ONE-rank group on one GPU
     distributed = world > 1 or os.environ.get("MOMA_BENCH_FORCE_DIST") == "1"
     if distributed:
-        dist.init_process_group(os.environ.get("MOMA_BENCH_BACKEND", "nccl"))     # "nccl" = RCCL over xGMI
+        import datetime
+        os.environ.setdefault("NCCL_DEBUG", "WARN")               # (also under a launcher that is not ours: RCCL says why it failed)
+        # a collective that cannot complete raises after this long instead of after torch's default ten minutes -- inside the
+        # rank's own deadline (rank_watchdog), so that the error, not the watchdog, is what the log ends with
+        dist.init_process_group(os.environ.get("MOMA_BENCH_BACKEND", "nccl"),     # "nccl" = RCCL over xGMI
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("MOMA_BENCH_COLLECTIVE_TIMEOUT", "300"))))
         if dist.get_backend() == "nccl":
             # first contact with the communicator HERE, not inside the model wrap: RCCL builds its rings lazily at the first collective
             t = torch.ones(1, device=dev)

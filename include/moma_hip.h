@@ -149,6 +149,17 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
                          float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq,
                          void* workspace, size_t workspace_bytes, int qdtype, int prec,
                          moma_stream_t stream, void* ev_begin, void* ev_end, void* ev_call_end);
+/* K2 + K3 in one call: moma_infonce_fused_q(...) followed by the enqueue of `rows` [n,d] at ring pointer `index`
+ * (MoCo.forward, MoMA/mem_moco.py:77-100: logits from the PRE-enqueue queue, then _update_memory).  Where the call ends in the
+ * combine launch (the bf16 policy's one-pass and two-pass paths) the enqueue rides on THAT launch -- extra workgroups behind every
+ * read of the queue -- instead of a launch of its own; elsewhere it is issued behind the call.  Same results as the two calls.
+ *   queue     : what K2 reads, written in place: fp32 rows (qdtype F32) or rows rounded to bf16 (qdtype BF16);
+ *   queue_f32 : NULL, or -- qdtype BF16 only -- the fp32 queue whose bf16 mirror `queue` is: both take the rows (moma_enqueue_mirror).
+ * The ring pointer stays with the caller (a host integer: bit-exact contract); n = 0 is K2 alone. */
+int moma_infonce_fused_enqueue(const float* q, const void* q_packed, const float* k, void* queue, int B, int d, int K,
+                               float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                               size_t workspace_bytes, int qdtype, int prec, const float* rows, int n, int64_t index,
+                               float* queue_f32, moma_stream_t stream, void* ev_begin, void* ev_end, void* ev_call_end);
 
 /* Several InfoNCE terms over queues of the same shape in ONE sweep -- replaces the 2 / 4 `_compute_logit` calls + CrossEntropy of
  * the dual-queue memories MoCoST.forward / MoCoSSTT.forward (MoMA/mem_moco.py:165-253):

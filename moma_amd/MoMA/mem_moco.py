@@ -119,20 +119,22 @@ class MoCo(BaseMoCo):
         shadow = None
         if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
             shadow = self._bf16_shadow()
-        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack)
-        self._enqueue(all_k if all_k is not None else k, shadow)
+        rows = (all_k if all_k is not None else k).detach().contiguous().float()
+        loss_rows, _lse, top1 = ops.infonce_fused(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack,
+                                                  enq=self._enqueue_job(rows, shadow))
+        self._enqueued(rows.size(0), shadow)
         return loss_rows.mean(), top1.float().mean(0, keepdim=True) * 100.0
 
-    def _enqueue(self, all_k, shadow):
-        """_update_memory + _update_pointer (reference :97-99), the bf16 mirror of an fp32 queue written by the same launch"""
+    def _enqueue_job(self, rows, shadow):
+        """(rows, pointer, fp32 queue | None) for ops.infonce_fused*(enq=...): _update_memory (reference :97-99) on the K2 call's last
+        launch -- behind every read of the pre-enqueue queue, as MoCo.forward orders them -- instead of a launch of its own"""
+        return (rows, self.index, self.memory if shadow is not None else None)
+
+    def _enqueued(self, n, shadow):
+        """host-side bookkeeping of an enqueue the K2 call carried: the mirror is current, the pointer moves (_update_pointer)"""
         if shadow is not None:
-            # fp32 `memory` and its bf16 mirror in ONE launch (same rows, rounded to bf16: the mirror stays exact)
-            with torch.no_grad():
-                ops.enqueue_mirror_(self.memory, shadow, all_k.detach().contiguous().float(), self.index)
             self._shadow_key = (self.memory.data_ptr(), self.memory._version, tuple(self.memory.shape))
-        else:
-            self._update_memory(all_k, self.memory)
-        self._update_pointer(all_k.size(0))
+        self._update_pointer(n)
 
     def forward_fused_into(self, q, k, all_k, qpack_buf, out):
         """forward_fused without autograd, results into caller-owned static buffers (`out`: ops.K2Buffers) -- the form a step
@@ -142,8 +144,10 @@ class MoCo(BaseMoCo):
         shadow = None
         if self.memory.dtype == torch.float32 and ops.prec_code(self.precision) == ops.PREC_BF16 and self.memory.is_cuda:
             shadow = self._bf16_shadow()
-        ops.infonce_fused_into(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack_buf, out)
-        self._enqueue(all_k if all_k is not None else k, shadow)
+        rows = (all_k if all_k is not None else k).detach().contiguous().float()
+        ops.infonce_fused_into(q, k, self.memory if shadow is None else shadow, self.T, self.precision, qpack_buf, out,
+                               enq=self._enqueue_job(rows, shadow))
+        self._enqueued(rows.size(0), shadow)
 
 
 class MoCoAtt(BaseMoCo):

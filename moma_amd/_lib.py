@@ -40,6 +40,7 @@ SIGNATURES = {
     "moma_infonce_fused_ex": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p]),
     "moma_infonce_qpack_bytes": (_z, [_i, _i]),
     "moma_infonce_fused_q": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
+    "moma_infonce_fused_enqueue": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p, _i, _l, _p, _p, _p, _p, _p]),
     "moma_infonce_fused_multi_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "moma_infonce_fused_multi": (_i, [_p, _i, _i, _i, _i, _f, _p, _z, _i, _i, _p]),
     "moma_mha_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -164,10 +164,13 @@ int moma_infonce_fused_ex(const float* q, const float* k, const void* queue, int
 
 size_t moma_infonce_qpack_bytes(int B, int d) { return infonce_qpack_bytes(B, d); }
 
-int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
-                         float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
-                         size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end,
-                         void* ev_call_end) {
+// K2 (+ K3 when `job` names rows): the enqueue rides on the call's last launch where the path has a combine launch to carry it
+// (*carried = 1), else the caller launches it behind the call
+static int fused_impl(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
+                      float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                      size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end,
+                      void* ev_call_end, const EnqueueJob* job, int* carried) {
+    if (carried) *carried = 0;
     if (!q || !k || !queue || !loss_rows || !lse || !top1 || !workspace) return MOMA_E_NULL;
     if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
@@ -176,9 +179,11 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     hipStream_t st = (hipStream_t)stream;
     if (q_packed && (misaligned(q_packed, 16) || infonce_qpack_bytes(B, d) == 0 || !infonce_flash_supported(B, d, K, qdtype, prec)))
         return q_packed && misaligned(q_packed, 16) ? MOMA_E_ALIGN : MOMA_E_UNSUPPORTED;
-    if (infonce_flash_supported(B, d, K, qdtype, prec))
+    if (infonce_flash_supported(B, d, K, qdtype, prec)) {
+        if (carried) *carried = 1;
         return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,
-                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed, (hipEvent_t)ev_call_end));
+                                           (hipEvent_t)ev_begin, (hipEvent_t)ev_end, q_packed, (hipEvent_t)ev_call_end, job));
+    }
     if (infonce_f32_flash_supported(B, d, K, qdtype, prec))      // exact fp32, fp32 queue: one pass, no [B,K+1] logits
     {
         const int rc = hip_rc(launch_infonce_f32_flash(q, k, (const float*)queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, st,
@@ -209,6 +214,34 @@ int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, c
     if (dq) rc = moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);
     if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
     return rc;
+}
+
+int moma_infonce_fused_q(const float* q, const void* q_packed, const float* k, const void* queue, int B, int d, int K,
+                         float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                         size_t workspace_bytes, int qdtype, int prec, moma_stream_t stream, void* ev_begin, void* ev_end,
+                         void* ev_call_end) {
+    return fused_impl(q, q_packed, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, workspace_bytes, qdtype, prec, stream,
+                      ev_begin, ev_end, ev_call_end, nullptr, nullptr);
+}
+
+int moma_infonce_fused_enqueue(const float* q, const void* q_packed, const float* k, void* queue, int B, int d, int K,
+                               float inv_T, float* loss_rows, float* lse, int32_t* top1, float* dq, void* workspace,
+                               size_t workspace_bytes, int qdtype, int prec, const float* rows, int n, int64_t index,
+                               float* queue_f32, moma_stream_t stream, void* ev_begin, void* ev_end, void* ev_call_end) {
+    if (n < 0 || K <= 0 || index < 0 || index >= K) return MOMA_E_SHAPE;
+    if (n > 0 && !rows) return MOMA_E_NULL;
+    if (bad_dt(qdtype)) return MOMA_E_DTYPE;
+    if (queue_f32 && qdtype != MOMA_DT_BF16) return MOMA_E_DTYPE;          // (a mirror is the bf16 image of an fp32 queue)
+    if (n > 0 && (misaligned(rows, 4) || misaligned(queue, qdtype == MOMA_DT_BF16 ? 2 : 4) || (queue_f32 && misaligned(queue_f32, 4))))
+        return MOMA_E_ALIGN;
+    EnqueueJob job{qdtype == MOMA_DT_BF16 ? queue : nullptr, qdtype == MOMA_DT_BF16 ? queue_f32 : (float*)queue, rows, n, index, K, d};
+    int carried = 0;
+    const int rc = fused_impl(q, q_packed, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, workspace_bytes, qdtype, prec,
+                              stream, ev_begin, ev_end, ev_call_end, n > 0 ? &job : nullptr, &carried);
+    if (rc != MOMA_OK || carried || n == 0) return rc;
+    // a path without a combine launch (exact fp32, staged): the enqueue as its own launch, behind the call on the stream
+    if (queue_f32) return hip_rc(launch_enqueue_mirror(queue_f32, queue, rows, n, index, K, d, (hipStream_t)stream));
+    return hip_rc(launch_enqueue(queue, rows, n, index, K, d, qdtype, (hipStream_t)stream));
 }
 
 size_t moma_infonce_fused_multi_workspace_bytes(int n_terms, int B, int d, int K, int qdtype, int prec) {

@@ -125,10 +125,20 @@ hipError_t launch_ema(const int64_t* table, int n_tensors, int64_t total_blocks,
 bool infonce_flash_supported(int B, int d, int K, int qdtype, int prec);
 size_t infonce_flash_workspace_bytes(int B, int d, int K);
 int set_k2_target_wg(int n);                            // debug knob of the K2 plan (moma_debug_set_k2_target_wg)
+// the enqueue that follows a K2 call (MoMA/mem_moco.py:97-99), carried by the call's LAST launch where there is one to carry it
+struct EnqueueJob {
+    void* queue16;        // bf16 queue rows are rounded into (the queue K2 has just read), or nullptr
+    float* queue32;       // fp32 queue (alone, or next to its bf16 mirror `queue16`), or nullptr
+    const float* rows;    // [n, d] fp32
+    int n;                // 0: nothing to enqueue
+    int64_t index;        // ring pointer: rows[i] -> slot (index + i) mod K
+    int K, d;
+};
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
                                 hipStream_t st, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                                const void* q_packed = nullptr, hipEvent_t ev_call_end = nullptr);
+                                const void* q_packed = nullptr, hipEvent_t ev_call_end = nullptr,
+                                const EnqueueJob* enq = nullptr);
 size_t infonce_qpack_bytes(int B, int d);
 bool infonce_multi_supported(int n_terms, int B, int d, int K, int qdtype, int prec);
 size_t infonce_multi_workspace_bytes(int n_terms, int B, int d, int K);

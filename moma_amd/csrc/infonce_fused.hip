@@ -1818,7 +1818,8 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
                                                      float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                      int32_t* __restrict__ top1, float* __restrict__ dq,
                                                      long slab_stride, int cg, int tpb,
-                                                     const float* __restrict__ ref_part) {
+                                                     const float* __restrict__ ref_part, const int by) {
+    // by: the block's row in the combine grid (blockIdx.y, less the rows that carry an enqueue in front of it)
     // ref_part: per (chunk, row) reference of the O partials when it is not m_part (wide rows: the integer references of pass 1)
     // tpb: column tiles per block (grid.y = ceil(D/32 / tpb)).  Every block repeats the row statistics of its 8 rows: 16x at
     // d = 512 with tpb = 1 (cheap); wide rows take 4 tiles per block (10x instead of 40x at d = 1280) in the same single launch.
@@ -1928,7 +1929,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
         if (l32 == 0) {
             rowc[rr][0] = 1.f / L;
             rowc[rr][1] = p0u / L - 1.f;
-            if (live && blockIdx.y == 0) {
+            if (live && by == 0) {
                 lse_out[b] = lse;
                 loss_rows[b] = lse - s0;
                 top1[b] = (s0l >= X) ? 1 : 0;
@@ -1948,7 +1949,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
         //      16.4 -> 15.6 - 15.9 us per combine -- the tiles were not what the wide-row combine waits for; its per-block row
         //      statistics are (1 tile per block, 4x the blocks: 22.3 us; 8 tiles: 21.7).
         if (tpb == TB && nparts <= 64) {
-            const int c0 = blockIdx.y * TB;
+            const int c0 = by * TB;
             uint4 v[TB][8];
 #pragma unroll
             for (int t = 0; t < TB; ++t) {
@@ -2002,7 +2003,7 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
             return;
         }
     }
-    for (int c = blockIdx.y * tpb; c < min((int)(blockIdx.y + 1) * tpb, D / 32); ++c) {
+    for (int c = by * tpb; c < min((by + 1) * tpb, D / 32); ++c) {
     const int sl = c >> 4, cl = c & 15;
     const int nct = min(16, D / 32 - 16 * sl);
     const long wb_stride = (long)nct * 2 * 64;                           // uint4 per wave block
@@ -2056,6 +2057,39 @@ __device__ __forceinline__ void infonce_combine_body(const float* __restrict__ q
     }
 }
 
+// K3 inside the combine launch (round 6).  The enqueue must follow the LAST read of the queue by this K2 call (read old, then
+// enqueue: MoMA/mem_moco.py:89-99) -- and the combine launch sits behind the passes over the queue on the stream, every workgroup
+// of which has finished: extra rows of the combine grid (blockIdx.y < ey) copy the B key rows into the ring -- fp32 rows into an
+// fp32 queue, rounded to bf16 into a bf16 queue / mirror, both from one read -- instead of a launch of their own (4.4 us of pure
+// dispatch in the step).  Semantics of enqueue_kernel (queue.hip): slot (index + i) mod K; with n > K a slot rewritten by a later
+// row is skipped, so the result is the serial index_copy_ without a write race.
+__device__ __forceinline__ void enqueue_rows(const EnqueueJob& e, int blk, int nblk) {
+    const int d = e.d;
+    bf16_raw* q16 = reinterpret_cast<bf16_raw*>(e.queue16);
+    const bool vec = d % 4 == 0 && (((uintptr_t)e.rows | (uintptr_t)e.queue32) & 15) == 0 && ((uintptr_t)e.queue16 & 7) == 0;
+    for (int i = blk; i < e.n; i += nblk) {
+        if ((int64_t)i + e.K < e.n) continue;
+        const int64_t slot = (e.index + i) % e.K;
+        const float* src = e.rows + (int64_t)i * d;
+        if (vec) {
+            for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                if (e.queue32) *reinterpret_cast<float4*>(e.queue32 + slot * d + c) = v;
+                if (q16) {
+                    ushort4 o;
+                    o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                    *reinterpret_cast<ushort4*>(q16 + slot * d + c) = o;
+                }
+            }
+        } else {
+            for (int c = threadIdx.x; c < d; c += 256) {
+                if (e.queue32) e.queue32[slot * d + c] = src[c];
+                if (q16) q16[slot * d + c] = f32_to_bf16(src[c]);
+            }
+        }
+    }
+}
+
 template <int TB>
 __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                int B, int D, float inv_T, int nchunk, int Bpad,
@@ -2066,9 +2100,23 @@ __global__ __launch_bounds__(256) void infonce_combine_kernel(const float* __res
                                                                float* __restrict__ loss_rows, float* __restrict__ lse_out,
                                                                int32_t* __restrict__ top1, float* __restrict__ dq,
                                                                long slab_stride, int cg, int tpb,
-                                                               const float* __restrict__ ref_part) {
+                                                               const float* __restrict__ ref_part, EnqueueJob enq, int ey) {
+    // the first `ey` rows of the grid carry the enqueue (FIRST in dispatch order: they run beside the combine's own workgroups;
+    // behind them they were a 3 us tail of their own -- a dependent load -> store chain with the chip already drained)
+    if ((int)blockIdx.y < ey) {                      // (block-uniform; ey = 0 when nothing rides along)
+        enqueue_rows(enq, (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, ey * (int)gridDim.x);
+        return;
+    }
     infonce_combine_body<TB>(q, k, B, D, inv_T, nchunk, Bpad, o_part, m_part, l_part, x_part, loss_rows, lse_out, top1, dq, slab_stride,
-                             cg, tpb, ref_part);
+                             cg, tpb, ref_part, (int)blockIdx.y - ey);
+}
+
+// rows of the combine grid that carry the enqueue: about 64 workgroups for the B key rows (a row of 512 floats is half a pass of a
+// 256-thread workgroup), none without a job
+static int enqueue_grid_rows(const EnqueueJob* e, int gx) {
+    if (e == nullptr || e->n <= 0) return 0;
+    int want = e->n < 64 ? e->n : 64;
+    return (want + gx - 1) / gx;
 }
 
 // ---- several InfoNCE terms in ONE sweep (the dual-queue memories MoCoST / MoCoSSTT, reference MoMA/mem_moco.py:165-253:
@@ -2149,7 +2197,7 @@ __global__ __launch_bounds__(256) void infonce_combine_multi_kernel(MultiArgs a,
     const MultiTerm t = pick_term(a, term);
     infonce_combine_body(t.q, t.k, B, D, inv_T, nchunk, Bpad, o_part + term * o_term_stride, m_part + term * term_rows,
                          l_part + term * term_rows, x_part + term * term_rows, t.loss_rows, t.lse, t.top1, t.dq, 0L, 1, 1,
-                         m_part + term * term_rows);
+                         m_part + term * term_rows, (int)blockIdx.y);
 }
 
 struct FlashPlan {
@@ -2287,7 +2335,10 @@ size_t infonce_qpack_bytes(int B, int d) {
 // producer of q (K1's proj epilogue, k1_fast.hip) -- the pre-pack launch is skipped.
 hipError_t launch_infonce_flash(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
                                 float* loss_rows, float* lse, int32_t* top1, float* dq, void* ws, int qdtype,
-                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed, hipEvent_t ev_call_end) {
+                                hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const void* q_packed, hipEvent_t ev_call_end,
+                                const EnqueueJob* enq) {
+    const EnqueueJob no_job{nullptr, nullptr, nullptr, 0, 0, 1, d};
+    const EnqueueJob job = (enq && enq->n > 0) ? *enq : no_job;
     if (B <= SMALL_B_MAX && dq != nullptr && one_pass_dim(d)) {
         // ---- small batches: key-half split (infonce_small_kernel), two virtual chunks per workgroup, 64 padded rows
         const SmallPlan sp = small_plan(K, d);
@@ -2317,8 +2368,9 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
 #undef MOMA_SMALL_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(Bp / 8, d / 32), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
-                              d, inv_T, nwg, Bp, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
+        const int ny = d / 32, ey = enqueue_grid_rows(&job, Bp / 8);
+        hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(Bp / 8, ny + ey), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+                              d, inv_T, nwg, Bp, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part, job, ey);
         return hipGetLastError();
     }
     const FlashPlan p = plan(B, K, d);
@@ -2422,9 +2474,10 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
             // statistics, and those, not the tiles, are what the wide-row combine spends its time on)
             int tpb = 4;
             const int nty = dq ? (d / 32 + tpb - 1) / tpb : 1;
-            hipExtLaunchKernelGGL((infonce_combine_kernel<4>), dim3(p.Bpad / 8, nty), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
+            const int ey = enqueue_grid_rows(&job, p.Bpad / 8);
+            hipExtLaunchKernelGGL((infonce_combine_kernel<4>), dim3(p.Bpad / 8, nty + ey), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q, k, B,
                                   d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq,
-                                  (long)(slab_bytes / 16), cg, tpb, wide_ref);
+                                  (long)(slab_bytes / 16), cg, tpb, wide_ref, job, ey);
         }
         return hipGetLastError();
     }
@@ -2448,8 +2501,9 @@ hipError_t launch_infonce_flash(const float* q, const float* k, const void* queu
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // (ev_call_end rides on the combine's dispatch: ev_begin .. ev_call_end spans the call's kernels, dispatch to dispatch)
-    hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(p.Bpad / 8, dq ? d / 32 : 1), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,
-                          k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part);
+    const int ny = dq ? d / 32 : 1, ey = enqueue_grid_rows(&job, p.Bpad / 8);
+    hipExtLaunchKernelGGL((infonce_combine_kernel<1>), dim3(p.Bpad / 8, ny + ey), dim3(256), 0, st, (hipEvent_t) nullptr, ev_call_end, 0, q,
+                          k, B, d, inv_T, p.nchunk, p.Bpad, o_part, m_part, l_part, x_part, loss_rows, lse, top1, dq, 0L, 1, 1, m_part, job, ey);
     return hipGetLastError();
 }
 

@@ -320,21 +320,38 @@ class K2Buffers:
                               dtype=torch.uint8)
 
 
-def _infonce_fused_launch(q, k, queue, T, prec, qpack_buf, loss_rows, lse, top1, dq, ws):
+def _infonce_fused_launch(q, k, queue, T, prec, qpack_buf, loss_rows, lse, top1, dq, ws, enq=None):
+    """enq: None, or (rows [n,d] fp32, ring pointer, fp32 queue whose bf16 mirror `queue` is | None) -- the enqueue that follows
+    the call (MoMA/mem_moco.py:97-99) rides on the call's last launch (moma_infonce_fused_enqueue)"""
     lib = _lib.load()
     B, d = q.shape
     K = queue.shape[0]
     ev0, ev1, ev2 = _KERNEL_EVENTS() if _KERNEL_EVENTS is not None else (None, None, None)
     with _timed("moma_infonce_fused"):
-        check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack_buf), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
-                                       _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), _qdtype(queue), prec,
-                                       _stream(), C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
-              "moma_infonce_fused")
+        if enq is None:
+            check(lib.moma_infonce_fused_q(_ptr(q), _ptr(qpack_buf), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
+                                           _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), _qdtype(queue), prec,
+                                           _stream(), C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
+                  "moma_infonce_fused")
+        else:
+            rows, index, queue_f32 = enq
+            _dev(rows, "rows")
+            if rows.dim() != 2 or rows.shape[1] != d or not rows.is_contiguous():
+                raise ValueError(f"rows must be contiguous [n,{d}], got {tuple(rows.shape)}")
+            if queue_f32 is not None:
+                _dev(queue_f32, "queue_f32")
+                if queue_f32.shape != queue.shape or queue.dtype != torch.bfloat16:
+                    raise ValueError("queue_f32 goes with its bf16 mirror of the same shape as `queue`")
+            check(lib.moma_infonce_fused_enqueue(_ptr(q), _ptr(qpack_buf), _ptr(k), _ptr(queue), B, d, K, float(1.0 / T),
+                                                 _ptr(loss_rows), _ptr(lse), _ptr(top1), _ptr(dq), _ptr(ws), ws.numel(), _qdtype(queue),
+                                                 prec, _ptr(rows), rows.shape[0], int(index), _ptr(queue_f32), _stream(),
+                                                 C.c_void_p(ev0), C.c_void_p(ev1), C.c_void_p(ev2)),
+                  "moma_infonce_fused_enqueue")
 
 
-def infonce_fused_into(q, k, queue, T: float, prec, qpack_buf, out: K2Buffers) -> None:
+def infonce_fused_into(q, k, queue, T: float, prec, qpack_buf, out: K2Buffers, enq=None) -> None:
     """moma_infonce_fused into caller-owned buffers, no autograd: loss_rows / lse / top1 / dq (= d sum(loss_rows) / dq) land in
-    `out`.  qpack_buf: the packed image of q its producer wrote (or None: K2 packs q itself)."""
+    `out`.  qpack_buf: the packed image of q its producer wrote (or None: K2 packs q itself).  enq: see _infonce_fused_launch."""
     q = q.detach(); k = k.detach()
     _check_qk(_dev(q, "q"), _dev(k, "k"), queue)
     if (q.shape[0], q.shape[1], queue.shape[0]) != out.shape:
@@ -342,7 +359,7 @@ def infonce_fused_into(q, k, queue, T: float, prec, qpack_buf, out: K2Buffers) -
     pc = prec_code(prec)
     if qpack_buf is not None and not (queue.dtype == torch.bfloat16 and pc == PREC_BF16):
         qpack_buf = None
-    _infonce_fused_launch(q, k, queue, float(T), pc, qpack_buf, out.loss_rows, out.lse, out.top1, out.dq, out.ws)
+    _infonce_fused_launch(q, k, queue, float(T), pc, qpack_buf, out.loss_rows, out.lse, out.top1, out.dq, out.ws, enq)
 
 
 class StaticK2Loss(torch.autograd.Function):
@@ -364,7 +381,7 @@ class _InfoNCEFused(torch.autograd.Function):
     """One pass over the queue: per-row CE(label 0) loss, lse, top-1 flag and d(sum loss)/dq."""
 
     @staticmethod
-    def forward(ctx, q, k, queue, T, prec, qpack=None):
+    def forward(ctx, q, k, queue, T, prec, qpack=None, enq=None):
         lib = _lib.load()
         q = q.contiguous(); k = k.contiguous()
         _check_qk(q, k, queue)
@@ -378,7 +395,7 @@ class _InfoNCEFused(torch.autograd.Function):
         dq = torch.empty(B, d, device=dev, dtype=torch.float32) if need_grad else None
         ws_bytes = lib.moma_infonce_fused_workspace_bytes(B, d, K, _qdtype(queue), prec)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        _infonce_fused_launch(q, k, queue, T, prec, qpack, loss_rows, lse, top1, dq, ws)
+        _infonce_fused_launch(q, k, queue, T, prec, qpack, loss_rows, lse, top1, dq, ws, enq)
         if need_grad:
             ctx.save_for_backward(dq)
         ctx.mark_non_differentiable(lse, top1)
@@ -387,7 +404,7 @@ class _InfoNCEFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_lse, g_top1):
         (dq,) = ctx.saved_tensors
-        return dq * g_loss.unsqueeze(1), None, None, None, None, None
+        return dq * g_loss.unsqueeze(1), None, None, None, None, None, None
 
 
 def debug_set_k2_target_wg(n: int) -> int:
@@ -400,9 +417,10 @@ def debug_set_k2_target_wg(n: int) -> int:
     return prev
 
 
-def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = None, enq=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (loss_rows [B], lse [B], top1 [B] int32).  loss_kd = loss_rows.mean().
-    qpack: a QPack that the producer of q filled (ignored unless it was written from exactly this q and T)."""
+    qpack: a QPack that the producer of q filled (ignored unless it was written from exactly this q and T).
+    enq: None, or (rows, ring pointer, fp32 queue | None): the enqueue behind the pass rides on the call (_infonce_fused_launch)."""
     buf = None
     if qpack is not None and q.is_contiguous() and qpack.matches(q, T) and queue.dtype == torch.bfloat16 \
             and prec_code(prec) == PREC_BF16:
@@ -414,7 +432,7 @@ def infonce_fused(q, k, queue, T: float, prec="fp32", qpack: "QPack | None" = No
                 b = _InfoNCEFused.apply(q.detach(), k.detach(), queue, float(T), prec_code(prec), None)[1]
             if not torch.equal(a, b):
                 raise MomaHipError("QPack: the packed image of q does not match q (written behind autograd's version counter?)")
-    return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec), buf)
+    return _InfoNCEFused.apply(q, k, queue, float(T), prec_code(prec), buf, enq)
 
 
 class _InfoNCEFusedMulti(torch.autograd.Function):

@@ -809,6 +809,56 @@ def test_moco_fp32_storage_uses_bf16_mirror(ops):
     assert torch.equal(m32._shadow[B:], m32.memory.to(torch.bfloat16)[B:])
 
 
+@pytest.mark.parametrize("B,d,K,n,index,qdt,prec,mirror", [
+    (256, 512, 65536, 256, 65400, "bf16", "bf16", False),     # the bench shape; the enqueue wraps around the ring
+    (64, 512, 16384, 64, 0, "bf16", "bf16", False),           # small-batch kernel (the reference's run-script shape)
+    (100, 256, 1000, 100, 990, "bf16", "bf16", True),         # fp32 queue + its bf16 mirror, ragged B, K not a multiple of 32
+    (32, 128, 40, 96, 7, "bf16", "bf16", False),              # n = 3B > K: last writer wins
+    (256, 1280, 8192, 256, 8000, "bf16", "bf16", False),      # wide rows: the enqueue rides on the wide combine
+    (64, 512, 4096, 64, 4090, "fp32", "fp32", False),         # exact fp32 (no combine launch): issued behind the call
+    (48, 384, 2048, 0, 5, "bf16", "bf16", False),             # n = 0: K2 alone
+])
+def test_k2_call_carries_the_enqueue(ops, B, d, K, n, index, qdt, prec, mirror):
+    """moma_infonce_fused_enqueue (round 6: K3 inside the combine launch) == moma_infonce_fused_q followed by moma_enqueue(_mirror),
+    bit for bit: the loss / lse / top-1 / dq come from the PRE-enqueue queue (MoMA/mem_moco.py:89-99: read old, then enqueue) and the
+    queue afterwards holds rows[i] in slot (index + i) mod K (reference :17-27)."""
+    torch.manual_seed(B + d + K)
+    dev = "cuda"
+    q = torch.nn.functional.normalize(torch.randn(B, d, device=dev))
+    k = torch.nn.functional.normalize(q + 0.3 * torch.randn(B, d, device=dev))
+    rows = torch.nn.functional.normalize(torch.randn(max(n, 1), d, device=dev))[:n].contiguous()
+    q32 = torch.nn.functional.normalize(torch.randn(K, d, device=dev))
+    qstore = q32.to(torch.bfloat16) if qdt == "bf16" else q32.clone()
+
+    def run(fused):
+        qq = q.clone().requires_grad_(True)
+        store = qstore.clone()
+        full = q32.clone() if mirror else None
+        if fused:
+            loss_rows, lse, top1 = ops.infonce_fused(qq, k, store, 0.15, prec, enq=(rows, index, full))
+        else:
+            loss_rows, lse, top1 = ops.infonce_fused(qq, k, store, 0.15, prec)
+            if n:
+                if mirror:
+                    ops.enqueue_mirror_(full, store, rows, index)
+                else:
+                    ops.enqueue_(store, rows, index)
+        loss_rows.sum().backward()
+        torch.cuda.synchronize()
+        return loss_rows.detach(), lse, top1, qq.grad, store, full
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or torch.equal(x, y)
+    # ... and against the oracle's ring buffer (fp32 rows; bf16 storage rounds them)
+    ref = q32.cpu().numpy().copy()
+    if n:
+        O.update_memory(ref, rows.cpu().numpy(), index)
+    want = torch.from_numpy(ref).to(dev)
+    assert torch.equal(a[4], want.to(a[4].dtype))
+    if mirror:
+        assert torch.equal(a[5], want)
+
+
 def test_dual_queue_memories_golden(ops, golden_dir):
     """MoCoST / MoCoSSTT (reference MoMA/mem_moco.py:165-253): logits vs the reference, queues + pointer bit-exact."""
     from moma_amd.MoMA.mem_moco import MoCoST, MoCoSSTT
