@@ -43,16 +43,22 @@ def _install_cpu_standins():
     def infonce_logits(q, k, queue, T, prec="fp32"):
         return torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().t()], dim=1) / T
 
-    def infonce_fused(q, k, queue, T, prec="fp32", qpack=None):
-        logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().clone().t()], dim=1) / T   # pre-enqueue snapshot
-        lse = torch.logsumexp(logits, dim=1)
-        top1 = (logits[:, 0] >= logits.max(dim=1).values).to(torch.int32)
-        return lse - logits[:, 0], lse.detach(), top1
-
     def enqueue_(queue, rows, index):
         K = queue.shape[0]
         ids = torch.fmod(torch.arange(rows.shape[0]) + index, K).long()
         queue.index_copy_(0, ids, rows.to(queue.dtype))
+
+    def infonce_fused(q, k, queue, T, prec="fp32", qpack=None, enq=None):
+        logits = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.float().clone().t()], dim=1) / T   # pre-enqueue snapshot
+        lse = torch.logsumexp(logits, dim=1)
+        top1 = (logits[:, 0] >= logits.max(dim=1).values).to(torch.int32)
+        if enq is not None:                                   # the enqueue the K2 call carries: read old, then enqueue
+            rows, index, full = enq
+            with torch.no_grad():
+                enqueue_(queue, rows, index)
+                if full is not None:
+                    enqueue_(full, rows, index)
+        return lse - logits[:, 0], lse.detach(), top1
 
     class EmaTable:
         def __init__(self, ps, es):
