@@ -379,3 +379,65 @@ def test_flat_wrap_safety_checks(tmp_path):
         assert r["self_test"] and r["auto_is_flat"] and r["layout_refused"] and r["gradset_refused"]
         assert r["n_coll"] == 1 and r["avg_ok"] and r["late_change_refused"]
     assert torch.equal(r0["state"], r1["state"]) and r0["state"][-11:-6].eq(1.0).all()     # rank 0's running_mean (rank 1 had 2.0); then var [5], count [1]
+
+
+def _ctl_fail_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import moma_amd.learning.ddp as ddp
+    res = {}
+    real = ddp.control_group
+
+    def flaky(group=None, force_new=False):
+        if rank == 1:
+            raise RuntimeError("no usable gloo transport on this rank")
+        return real(group, force_new)
+    ddp.control_group = flaky
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 2))
+    flat = ddp.FlatDataParallel(net)
+    res["ctl_none"] = flat._ctl is None                       # the SAME verdict on both ranks (rank 0 did get a group)
+    extra = nn.Linear(4, 1)
+    x = torch.randn(3, 4)
+    # degraded mode: the device-side exchange at the first step still refuses differing gradient sets on every rank
+    (flat(x).sum() + (extra(x).sum() if rank == 1 else 0.0)).backward()
+    params = flat.grad_params() + list(extra.parameters())
+    try:
+        flat.allreduce_grads(params)
+        res["refused"] = False
+    except RuntimeError as e:
+        res["refused"] = "gradient sets differ" in str(e)
+    for p in params:
+        p.grad = None
+    (flat(x).sum() + extra(x).sum()).backward()
+    res["n_coll"] = flat.allreduce_grads(params)
+    ddp.control_group = real
+    # the cache holds the data-group OBJECT: after a teardown and a new job in this process the old entry is not handed out
+    c0 = real()
+    res["cached"] = real() is c0
+    dist.barrier()
+    dist.destroy_process_group()
+    os.environ["MASTER_PORT"] = str(port + 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c1 = real()
+    res["fresh_after_reinit"] = c1 is not c0 and c1 is dist.group.WORLD
+    t = torch.ones(1)
+    dist.all_reduce(t, group=c1)
+    res["works"] = int(t.item()) == world
+    torch.save(res, f"{out}.rank{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_group_verdict_is_collective_and_the_cache_survives_a_reinit(tmp_path):
+    """ADVICE r5 (learning/ddp.py): creating the control group is a collective that may fail on ONE rank; that rank used to skip the
+    per-step agreement while the others blocked in it.  Now the ranks agree on whether they all hold one (MIN over the data
+    group); without it the gradient sets are still verified (device-side, first step / local change).  The cache is keyed on the
+    data-group object, not on an id() that a later job's group can reuse."""
+    out = str(tmp_path / "ctl")
+    port = _free_port()
+    mp.spawn(_ctl_fail_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in (torch.load(f"{out}.rank0"), torch.load(f"{out}.rank1")):
+        assert r["ctl_none"] and r["refused"] and r["n_coll"] == 1
+        assert r["cached"] and r["fresh_after_reinit"] and r["works"]
