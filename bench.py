@@ -659,6 +659,8 @@ def main():
     rec.events.clear()
     kev.pairs.clear()
     barrier()
+    if distributed:
+        phase("warmup_done")
     log(f"warm-up done; timing {a.steps} steps")
     opt.step_events = []
     sg = getattr(trainer, "_step_graphs", None)
