@@ -1258,74 +1258,20 @@ def test_effnet_weight_cache_is_transparent():
 
 @pytest.mark.parametrize("amp", [False, True])
 def test_effnet_helpers_match_stock_ops(amp):
-    """Whole EfficientNet-B0 forward + backward with the library's BN / depthwise / SE kernels against the same network
-    on stock PyTorch-ROCm ops (MIOpen BN, ATen depthwise, pooling + sigmoid + mul): logits, features, running statistics
-    and parameter gradients.  fp32 = tight; bf16 autocast = within the rounding of one bf16 pipeline versus another."""
-    from moma_amd.backbones import efficientnet as E
-    torch.manual_seed(0)
-    ref = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
-    new = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
-    new.load_state_dict(ref.state_dict())
-    sd_init = [v.clone() for v in ref.state_dict().values()]              # (the runs move the BatchNorm running statistics)
-    x = torch.randn(6, 3, 96, 96, device="cuda")
-
-    def run(net, hip):
-        saved = (E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE)
-        E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = ("hip", "hip", "hip", True) if hip else ("miopen", "aten", "aten", False)
-        try:
-            torch.manual_seed(5)                                   # same classifier-dropout mask in both runs
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                feats, logits = net(x, is_feat=True)
-            (logits.float().square().sum() + feats[-1].float().sum()).backward()
-            return logits.detach().float(), feats[-1].detach().float()
-        finally:
-            E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = saved
-
-    l0, f0 = run(ref, False)
-    l1, f1 = run(new, True)
-    # (bf16: two differently-rounded pipelines through 82 layers of a random-init net drift apart by ~10 % of the logit
-    #  range; the fp32 run is the tight comparison, the per-kernel tests bound each op to one bf16 rounding)
-    tol = 0.2 if amp else 2e-3
-    assert (l1 - l0).abs().max() / l0.abs().max() < tol
-    assert (f1 - f0).abs().max() / f0.abs().max() < tol
-    sd0, sd1 = ref.state_dict(), new.state_dict()
-    for k in sd0:
-        if "running_" in k:
-            torch.testing.assert_close(sd1[k], sd0[k], rtol=min(5 * tol, 0.3), atol=min(5 * tol, 0.3) * max(1.0, sd0[k].abs().max().item()), msg=k)
-        if "num_batches_tracked" in k:
-            assert int(sd1[k]) == int(sd0[k]) == 1
-    worst, who = 0.0, ""
-    gmax = max(p.grad.abs().max().item() for p in ref.parameters() if p.grad is not None)
-    for (n0, p0), (n1, p1) in zip(ref.named_parameters(), new.named_parameters()):
-        assert (p0.grad is None) == (p1.grad is None), n0
-        if p0.grad is not None:
-            # relative to the tensor's own scale, with a floor so that gradients that are zero up to rounding
-            # (e.g. of a scale that a following BatchNorm removes) do not dominate
-            e = ((p1.grad - p0.grad).abs().max() / p0.grad.abs().max().clamp_min((3e-2 if amp else 1e-4) * gmax)).item()
-            if e > worst:
-                worst, who = e, n0
-    assert worst < (0.6 if amp else 2e-2), (who, worst)
-    if amp:
-        # What the loose bf16 bounds above are made of: BOTH bf16 pipelines sit that far from the fp32 network (82 layers of a
-        # random-init net); the library's pipeline must not sit further from fp32 than the stock one does.
-        f32 = E.efficientnet_b0(num_classes=5, drop_connect_rate=0.0).cuda().train()
-        f32.load_state_dict({k: v for k, v in zip(ref.state_dict().keys(), sd_init)})
-        saved = (E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE)
-        E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = "miopen", "aten", "aten", False
-        try:
-            torch.manual_seed(5)
-            feats, logits = f32(x, is_feat=True)
-            (logits.float().square().sum() + feats[-1].float().sum()).backward()
-        finally:
-            E._BN_MODE, E._DW_MODE, E._SE_MODE, E._WCACHE = saved
-        l32, g32 = logits.detach(), {n: p.grad for n, p in f32.named_parameters() if p.grad is not None}
-        e_stock = ((l0 - l32).abs().max() / l32.abs().max()).item()
-        e_hip = ((l1 - l32).abs().max() / l32.abs().max()).item()
-        assert e_hip < 1.5 * e_stock + 1e-2, ("logits vs fp32", e_hip, e_stock)
-        gs = max(g.abs().max().item() for g in g32.values())
-        ge_stock = max(((p.grad - g32[n]).abs().max() / g32[n].abs().max().clamp_min(3e-2 * gs)).item() for n, p in ref.named_parameters() if n in g32)
-        ge_hip = max(((p.grad - g32[n]).abs().max() / g32[n].abs().max().clamp_min(3e-2 * gs)).item() for n, p in new.named_parameters() if n in g32)
-        assert ge_hip < 1.5 * ge_stock + 2e-2, ("gradients vs fp32", ge_hip, ge_stock)
+    """Whole EfficientNet-B0 forward + backward with the library's BN / depthwise / SE kernels against the same network on stock
+    PyTorch-ROCm ops (MIOpen BN, ATen depthwise, pooling + sigmoid + mul): logits, features, running statistics, parameter gradients
+    (tests/effnet_stock_compare.py holds the comparisons and their tolerances).  Run in a CHILD process: the stock kernels of the
+    reference side aborted once in five full-suite runs of round 6 (SIGABRT inside the stock backward, no message); a child killed
+    by a signal is started once more -- the code under test is the other side of the comparison --, a failed comparison is not."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "effnet_stock_compare.py")
+    for attempt in (1, 2):
+        r = subprocess.run([sys.executable, script, str(int(amp))], capture_output=True, text=True, timeout=900)
+        if r.returncode >= 0:
+            break
+        print(f"effnet_stock_compare.py died with signal {-r.returncode} (attempt {attempt}):\n{r.stderr[-1500:]}")
+    assert r.returncode == 0 and "effnet_stock_compare: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_graphed_teacher_forward_matches_eager():
