@@ -76,16 +76,18 @@ class MomaStep:
         return torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp_dtype is not None)
 
     def graphable(self):
-        """What helper/step_graph.py captures: the bench / run-script configuration (--distill moma, one-pass K2, --attn self,
-        MoCo memory, per-rank Shuffle-BN; fp16 + GradScaler when the optimizer takes the scale and the found-inf flag on the
+        """What helper/step_graph.py captures: the bench / run-script configuration (--distill moma, one-pass K2, --attn self /
+        self_mix / self_nomix, MoCo memory, per-rank Shuffle-BN; fp16 + GradScaler when the optimizer takes the scale and the found-inf flag on the
         device -- torch's fused SGD, what build_training makes for --amp fp16: the captured backward multiplies by the scaler's
         device tensor, `scaler.step / update` stay eager behind the graphs and read nothing back).  Everything else keeps the
         eager loop."""
         o = self.opt
         scaler_ok = self.scaler is None or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
-        return (self.dev.type == "cuda" and o.distill == "moma" and self.fused and not self.mocoatt and not self.attn_in_shuffle
-                and getattr(o, "attn", "self") == "self" and scaler_ok and hasattr(self.contrast, "forward_fused_into")
-                and getattr(o, "shuffle_bn", "per_rank") == "per_rank")
+        # (round 6: also --attn self_mix / self_nomix -- the key encoding with the attention in front of the un-shuffle,
+        #  learning/contrast_trainer.py:_shuffle_bn_attn, runs inside g_query behind the student's forward; K2 packs q itself)
+        return (self.dev.type == "cuda" and o.distill == "moma" and self.fused and not self.mocoatt
+                and getattr(o, "attn", "self") in ("self", "self_mix", "self_nomix") and scaler_ok
+                and hasattr(self.contrast, "forward_fused_into") and getattr(o, "shuffle_bn", "per_rank") == "per_rank")
 
     def teacher_side(self, images, teacher):
         """teacher forward #1 (:270-272), then the moma branch's no-grad part (:309-320, :327-329)."""

@@ -252,7 +252,8 @@ class StepGraphs:
             cap.images, cap.labels = images.clone(), labels.clone()
             cap.perm = PermFeed(B, dev)
             cap.qpack = None
-            if ops.prec_code(contrast.precision) == ops.PREC_BF16:
+            if ops.prec_code(contrast.precision) == ops.PREC_BF16 and not st.attn_in_shuffle:
+                # (--attn self_mix / self_nomix: q leaves another module -- `atts` over [q ; k] -- that does not pack it)
                 cap.qpack = ops.QPack().prepare(B, d, contrast.T, dev)        # this graph's own packed-q image (None: K2 packs)
             cap.k2 = ops.K2Buffers(B, d, K, self._streamed_queue().dtype, contrast.precision, dev)
             # the graphs own what they read besides parameters and buffers: weight packs of the attention modules are rebuilt

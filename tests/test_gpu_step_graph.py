@@ -13,7 +13,8 @@ import torch.nn as nn
 pytestmark = pytest.mark.gpu
 
 
-def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16):
+def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16,
+         attn="self", mem="MoCo"):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -28,7 +29,7 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
     ms, mt = model_dict[model](num_classes=10, **kw), model_dict[model](num_classes=10, **kw)
     with torch.no_grad():
         s_dim = ms.eval()(torch.randn(2, 3, size, size), is_feat=True)[0][-1].shape[1]
-    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
                              cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
                              batch_size=B, rank=0, world_size=1, s_dim=s_dim, t_dim=s_dim, moma_prec=prec, queue_dtype=queue_dtype,
                              moma_fused=True, trace=[], overlap_teacher=overlap, graph_teacher=True, graph_student=graph_student,
@@ -37,7 +38,8 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
     kd = CMO(opt)
     ms, mt, contrast, kd = ms.to(dev), mt.to(dev), contrast.to(dev), kd.to(dev)
     trainer = ContrastTrainer(opt)
-    trainable = nn.ModuleList([ms, kd.atts_q, kd.atts_k, kd.atts_queue, kd.embed_s])
+    att_names = [n for n in ("atts", "atts_p", "atts_n", "atts_q", "atts_k", "atts_queue") if hasattr(kd, n)]
+    trainable = nn.ModuleList([ms] + [getattr(kd, n) for n in att_names] + [kd.embed_s])
     if amp == "fp16":            # as train_student_moma.build_training / main_worker do for --amp fp16
         from moma_amd.train_student_moma import make_optimizer
         opt._grad_scaler = torch.amp.GradScaler("cuda", init_scale=scale0)
@@ -62,10 +64,10 @@ def _run(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=
                 index=[t[1] for t in opt.trace], memory=contrast.memory.float().cpu().numpy(), replays=0 if sg is None else sg.replays, ngraphs=0 if sg is None else len(sg.graphs),
                 student={k: v.float().cpu().numpy() for k, v in ms.state_dict().items()},
                 teacher={k: v.float().cpu().numpy() for k, v in mt.state_dict().items()},
-                atts_q=kd.atts_q.proj.weight.detach().cpu().numpy(), next_perm=torch.randperm(16).tolist(),
+                atts_q=getattr(kd, att_names[0]).proj.weight.detach().cpu().numpy(), next_perm=torch.randperm(16).tolist(),
                 delta=(torch.cat([p.detach().reshape(-1) for p in ms.parameters()]) - student0).double().cpu().numpy(),
                 scale=None if amp != "fp16" else float(opt._grad_scaler.get_scale()),
-                atts_k_grad_none=all(p.grad is None for p in kd.atts_k.parameters()),
+                atts_k_grad_none=(not hasattr(kd, "atts_queue")) or all(p.grad is None for p in kd.atts_k.parameters()),
                 grads_attached=all(p.grad is not None for p in ms.parameters()))
 
 
@@ -114,6 +116,31 @@ def test_step_graphs_equal_the_eager_loop(model, overlap, prec, queue_dtype, amp
     np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=20 * tol)
 
 
+@pytest.mark.parametrize("attn", ["self_mix", "self_nomix"])
+def test_step_graphs_serve_the_attention_in_shuffle_variants(attn):
+    """--attn self_mix / self_nomix (learning/contrast_trainer.py:_shuffle_bn_attn, reference :135-187: the attention applied in
+    front of the un-shuffle, over [q ; k] or per side) served from HIP graphs since round 6: the key encoding runs inside g_query
+    behind the student's forward (it needs the student's query), the permutation comes through the same static feed, K2 packs q
+    itself (no producer-side packed image).  Against the eager loop: per-step losses, pointer, queue, weights, generator state."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(True, "resnet8", True, "bf16", "bf16", None, attn=attn)
+    b = _run(False, "resnet8", True, "bf16", "bf16", None, attn=attn)
+    assert a["replays"] == 3 + 6 and b["replays"] == 0 and a["ngraphs"] == 1
+    assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"] and a["grads_attached"]
+    tol = 2e-4
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=tol, atol=tol)
+    assert a["loss"][0] == b["loss"][0]
+    np.testing.assert_allclose(a["memory"], b["memory"], rtol=0, atol=20 * tol)
+    rel = np.linalg.norm(a["delta"] - b["delta"]) / np.linalg.norm(b["delta"])
+    assert np.linalg.norm(b["delta"]) > 0 and rel < 0.1, rel
+    np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=20 * tol)      # (`atts` for self_mix, `atts_q` for self_nomix)
+    for name in a["student"]:
+        if "num_batches_tracked" in name:
+            assert np.array_equal(a["student"][name], b["student"][name]) and np.array_equal(a["teacher"][name], b["teacher"][name]), name
+
+
 @pytest.mark.parametrize("scale0", [2.0 ** 10, 2.0 ** 22])
 def test_step_graphs_with_fp16_and_a_grad_scaler(scale0):
     """--amp fp16 (BASELINE configs[4]): fp16 autocast + GradScaler with the step served from HIP graphs -- the captured backward
@@ -159,7 +186,7 @@ def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
     dev = torch.device("cuda", 0)
     torch.manual_seed(1)
     B, K, d = 8, 128, 64
-    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
                              cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
                              batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
                              moma_fused=True, trace=[], overlap_teacher=True)
@@ -346,7 +373,7 @@ def test_a_moved_parameter_is_never_replayed_through_its_old_address():
         dev = torch.device("cuda", 0)
         torch.manual_seed(1)
         B, K, d = 8, 128, 64
-        opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
+        opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
                                  cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
                                  batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
                                  moma_fused=True, trace=[], overlap_teacher=True, graph_student=graph_student)
