@@ -172,6 +172,16 @@ class MoCoAtt(BaseMoCo):
         return ((q * k).sum(dim=1) / self.T).contiguous()
 
     def forward(self, q, k, all_k=None, attn=None, criterion_kd=None):
+        logits, labels, k = self.forward_logits(q, k, attn=attn, criterion_kd=criterion_kd)
+        all_k = all_k if all_k is not None else k
+        self._update_memory(all_k, self.memory)
+        self._update_pointer(all_k.size(0))
+        return logits, labels
+
+    def forward_logits(self, q, k, attn=None, criterion_kd=None):
+        """`forward` up to the enqueue: (logits, labels, k behind its attention module) from a snapshot of the queue (reference
+        :111-147).  The step served from HIP graphs captures this part and issues the enqueue -- whose ring pointer is a host
+        integer -- between its graphs (helper/step_graph.py)."""
         bsz = q.size(0)
         k = k.detach()
         queue = self.memory.clone().detach()
@@ -202,10 +212,12 @@ class MoCoAtt(BaseMoCo):
         else:
             logits = self._compute_logit(q.contiguous(), k.contiguous(), queue.contiguous())
         labels = torch.zeros(bsz, dtype=torch.long, device=q.device)
-        all_k = all_k if all_k is not None else k
+        return logits, labels, k
+
+    def enqueue_keys(self, all_k):
+        """_update_memory + _update_pointer (reference :150-152) as a call of its own"""
         self._update_memory(all_k, self.memory)
         self._update_pointer(all_k.size(0))
-        return logits, labels
 
 
 class _DualQueue(BaseMoCo):

@@ -85,9 +85,14 @@ class MomaStep:
         scaler_ok = self.scaler is None or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
         # (round 6: also --attn self_mix / self_nomix -- the key encoding with the attention in front of the un-shuffle,
         #  learning/contrast_trainer.py:_shuffle_bn_attn, runs inside g_query behind the student's forward; K2 packs q itself)
-        return (self.dev.type == "cuda" and o.distill == "moma" and self.fused and not self.mocoatt
-                and getattr(o, "attn", "self") in ("self", "self_mix", "self_nomix") and scaler_ok
-                and hasattr(self.contrast, "forward_fused_into") and getattr(o, "shuffle_bn", "per_rank") == "per_rank")
+        if not (self.dev.type == "cuda" and o.distill == "moma" and scaler_ok and getattr(o, "shuffle_bn", "per_rank") == "per_rank"):
+            return False
+        if self.mocoatt:
+            # --mem MoCoAtt (round 6): the memory's cross-attention variant, the materialised logits and their CrossEntropy are
+            # captured with the query side (MoCoAtt.forward_logits); only the enqueue stays between the graphs
+            return getattr(o, "attn", "self") != "dual2" and hasattr(self.contrast, "forward_logits")
+        return (self.fused and getattr(o, "attn", "self") in ("self", "self_mix", "self_nomix")
+                and hasattr(self.contrast, "forward_fused_into"))
 
     def teacher_side(self, images, teacher):
         """teacher forward #1 (:270-272), then the moma branch's no-grad part (:309-320, :327-329)."""
@@ -216,6 +221,15 @@ class MomaStep:
         criterion = nn.CrossEntropyLoss()                                                 # reference sequence (:331-335)
         output = contrast(q=f_s, k=k, all_k=all_k)
         c_losses, _ = trainer._compute_loss_accuracy(logits=output[:-1], target=output[-1], criterion=criterion)
+        return c_losses[0]
+
+    def kd_logits_loss(self, fw):
+        """--mem MoCoAtt, the part of kd_term in front of the enqueue: cross-attention variant + logits from a snapshot of the
+        queue + CrossEntropy (reference MoMA/mem_moco.py:111-147, helper/loops_moma.py:331-335) -> loss_kd.  The graph-served step
+        captures this and issues `contrast.enqueue_keys` itself."""
+        opt, contrast = self.opt, self.contrast
+        logits, labels0, _k = contrast.forward_logits(q=fw["f_s"], k=fw["k"], attn=opt.attn, criterion_kd=self.criterion_kd)
+        c_losses, _ = self.trainer._compute_loss_accuracy(logits=[logits], target=labels0, criterion=nn.CrossEntropyLoss())
         return c_losses[0]
 
     def backward_part(self, fw, loss_kd):

@@ -18,6 +18,11 @@ captured ONCE into four HIP graphs and replayed, on the same two streams and wit
                              for the K2 call
                   eager      the data-parallel gradient all-reduce (learning/ddp.py: ONE flat collective), optimizer.step()
 
+Round 6, the widened loop paths: --attn self_mix / self_nomix run their key encoding (attention in front of the un-shuffle,
+learning/contrast_trainer.py:_shuffle_bn_attn) inside g_query and let K2 pack q itself; --mem MoCoAtt has no one-pass K2 -- its
+cross-attention variant, the logits against a snapshot of the queue and their CrossEntropy are part of g_query
+(MoCoAtt.forward_logits), and the eager part between the graphs is the enqueue alone.
+
 Why not ONE graph with the teacher side as a forked branch: measured (round 4, B = 256) a graph with the fork runs the step in
 43.5 ms against 40.1 ms eager and 42.0 ms for either without the second stream -- the runtime does not overlap the branches of
 one graph, it only adds their synchronisation.  Two graphs replayed on two streams overlap as the eager chains do.
@@ -114,9 +119,9 @@ class StepGraphs:
     def _streamed_queue(self):
         """the tensor K2 streams: `memory`, or the bf16 mirror of an fp32 `memory` under the bf16 policy (made here if absent)"""
         c = self.st.contrast
-        if c.memory.dtype == torch.float32 and ops.prec_code(c.precision) == ops.PREC_BF16:
+        if c.memory.dtype == torch.float32 and ops.prec_code(c.precision) == ops.PREC_BF16 and hasattr(c, "_bf16_shadow"):
             return c._bf16_shadow()
-        return c.memory
+        return c.memory                                       # (MoCoAtt reads `memory` itself: a snapshot per step)
 
     def _key(self, images, labels):
         st = self.st
@@ -210,7 +215,10 @@ class StepGraphs:
             cap.g_query.replay()
         fw = cap.fw
         with ops.trace_range("moma_step/K2_K3"):
-            st.contrast.forward_fused_into(fw["f_s"], fw["k"], fw["all_k"], None if cap.qpack is None else cap.qpack.buf, cap.k2)
+            if cap.k2 is None:                             # --mem MoCoAtt: g_query holds the logits (from its own snapshot of the queue)
+                st.contrast.enqueue_keys(fw["all_k"] if fw["all_k"] is not None else fw["k"])
+            else:
+                st.contrast.forward_fused_into(fw["f_s"], fw["k"], fw["all_k"], None if cap.qpack is None else cap.qpack.buf, cap.k2)
         with ops.trace_range("moma_step/g_bwd"):
             cap.g_bwd.replay()
         for m, dn in cap.bn_delta:
@@ -255,7 +263,10 @@ class StepGraphs:
             if ops.prec_code(contrast.precision) == ops.PREC_BF16 and not st.attn_in_shuffle:
                 # (--attn self_mix / self_nomix: q leaves another module -- `atts` over [q ; k] -- that does not pack it)
                 cap.qpack = ops.QPack().prepare(B, d, contrast.T, dev)        # this graph's own packed-q image (None: K2 packs)
-            cap.k2 = ops.K2Buffers(B, d, K, self._streamed_queue().dtype, contrast.precision, dev)
+            # (--mem MoCoAtt: no one-pass K2 -- logits and CrossEntropy are part of g_query, only the enqueue is issued eagerly)
+            cap.k2 = None if st.mocoatt else ops.K2Buffers(B, d, K, self._streamed_queue().dtype, contrast.precision, dev)
+            if st.mocoatt:
+                cap.qpack = None
             # the graphs own what they read besides parameters and buffers: weight packs of the attention modules are rebuilt
             # inside the graphs (into their pools) on every replay
             for m in kd.modules():
@@ -281,12 +292,16 @@ class StepGraphs:
             logit_t, k, all_k = self._record(cap.g_teacher, cs_side, lambda: st.teacher_side(cap.images, st.model_t))
             torch.clear_autocast_cache()
             pool = cap.g_student.pool()
-            fw = self._record(cap.g_query, cs, lambda: st.losses_and_query(feat_s, logit_s, logit_t, k, all_k, cap.images, cap.labels,
-                                                                          st.model_t, qpack=cap.qpack, prefetch=False), pool)
+            def query():
+                f = st.losses_and_query(feat_s, logit_s, logit_t, k, all_k, cap.images, cap.labels, st.model_t, qpack=cap.qpack, prefetch=False)
+                if st.mocoatt:
+                    f["loss_kd"] = st.kd_logits_loss(f)
+                return f
+            fw = self._record(cap.g_query, cs, query, pool)
             del feat_s, logit_s
 
             def bwd():
-                loss_kd = ops.StaticK2Loss.apply(fw["f_s"], cap.k2.loss_rows, cap.k2.dq).mean()
+                loss_kd = fw["loss_kd"] if st.mocoatt else ops.StaticK2Loss.apply(fw["f_s"], cap.k2.loss_rows, cap.k2.dq).mean()
                 loss = st.backward_part(fw, loss_kd)
                 return loss.detach(), loss_kd.detach()
             cap.loss, cap.loss_kd = self._record(cap.g_bwd, cs, bwd, pool)
@@ -303,8 +318,9 @@ class StepGraphs:
             cap.keepalive = list(type(trainer)._ema_tables.values())
             self.graphs[key] = cap
             if getattr(st.opt, "rank", 0) == 0:
+                mid = "losses + query + cross-attention logits | K3 eager" if st.mocoatt else "losses + query | K2 / K3 eager"
                 print(f"[moma] step captured into HIP graphs (batch {B}, variant {len(self.graphs)}): student forward || teacher "
-                      f"side | losses + query | K2 / K3 eager | backward")
+                      f"side | {mid} | backward")
             return cap
         except Exception as e:                                 # pragma: no cover - depends on the runtime
             print(f"[moma] HIP-graph capture of the training step failed ({type(e).__name__}: {e}); staying eager")

@@ -128,14 +128,43 @@ def test_step_graphs_serve_the_attention_in_shuffle_variants(attn):
     b = _run(False, "resnet8", True, "bf16", "bf16", None, attn=attn)
     assert a["replays"] == 3 + 6 and b["replays"] == 0 and a["ngraphs"] == 1
     assert a["index"] == b["index"] and a["next_perm"] == b["next_perm"] and a["grads_attached"]
-    tol = 2e-4
+    # (tolerances: the EAGER loop against itself is bit-identical in most runs and parts by up to 3e-3 in the losses / 0.04 in what
+    #  15 steps did to the weights in some -- MIOpen's weight gradients, scripts/diag_graph_noise.py; a stale gradient, a skipped
+    #  enqueue or a wrong permutation shows at the 1e-2 level and in the exact checks above)
+    tol = 5e-3
     np.testing.assert_allclose(a["loss"], b["loss"], rtol=tol, atol=tol)
     np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=tol, atol=tol)
     assert a["loss"][0] == b["loss"][0]
-    np.testing.assert_allclose(a["memory"], b["memory"], rtol=0, atol=20 * tol)
+    np.testing.assert_allclose(a["memory"], b["memory"], rtol=0, atol=2e-2)
     rel = np.linalg.norm(a["delta"] - b["delta"]) / np.linalg.norm(b["delta"])
-    assert np.linalg.norm(b["delta"]) > 0 and rel < 0.1, rel
-    np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=20 * tol)      # (`atts` for self_mix, `atts_q` for self_nomix)
+    assert np.linalg.norm(b["delta"]) > 0 and rel < 0.15, rel
+    np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=2e-2)          # (`atts` for self_mix, `atts_q` for self_nomix)
+    for name in a["student"]:
+        if "num_batches_tracked" in name:
+            assert np.array_equal(a["student"][name], b["student"][name]) and np.array_equal(a["teacher"][name], b["teacher"][name]), name
+
+
+@pytest.mark.parametrize("attn,prec", [("qk", "bf16"), ("self_qk", "fp32"), ("all", "bf16"), ("dual", "fp32"), ("self", "bf16")])
+def test_step_graphs_serve_the_cross_attention_memory(attn, prec):
+    """--mem MoCoAtt (reference MoMA/mem_moco.py:103-161; the loop path of SURVEY 8f n1) served from HIP graphs since round 6: the
+    memory's cross-attention variant, the logits against a snapshot of the queue and their CrossEntropy are captured with the query
+    side (MoCoAtt.forward_logits); only the enqueue -- its ring pointer is a host integer -- is issued between the graphs.  Against
+    the eager loop (MoCoAtt.forward): per-step losses, pointer after every step, final queue, weights, generator state."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(True, "resnet8", True, prec, "fp32", None, attn=attn, mem="MoCoAtt")
+    b = _run(False, "resnet8", True, prec, "fp32", None, attn=attn, mem="MoCoAtt")
+    assert a["replays"] == 3 + 6 and b["replays"] == 0 and a["ngraphs"] == 1
+    assert a["index"] == b["index"] and a["index"][-1] == (14 * 8 + 8 - 3) % 256
+    assert a["next_perm"] == b["next_perm"] and a["grads_attached"]
+    tol = 5e-3                                        # (eager against eager: see the test above)
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=tol, atol=tol)
+    assert a["loss"][0] == b["loss"][0]
+    np.testing.assert_allclose(a["memory"], b["memory"], rtol=0, atol=2e-2)
+    rel = np.linalg.norm(a["delta"] - b["delta"]) / np.linalg.norm(b["delta"])
+    assert np.linalg.norm(b["delta"]) > 0 and rel < 0.15, rel
+    np.testing.assert_allclose(a["atts_q"], b["atts_q"], rtol=0, atol=2e-2)
     for name in a["student"]:
         if "num_batches_tracked" in name:
             assert np.array_equal(a["student"][name], b["student"][name]) and np.array_equal(a["teacher"][name], b["teacher"][name]), name
@@ -186,7 +215,7 @@ def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
     dev = torch.device("cuda", 0)
     torch.manual_seed(1)
     B, K, d = 8, 128, 64
-    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
+    opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
                              cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
                              batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
                              moma_fused=True, trace=[], overlap_teacher=True)
@@ -373,7 +402,7 @@ def test_a_moved_parameter_is_never_replayed_through_its_old_address():
         dev = torch.device("cuda", 0)
         torch.manual_seed(1)
         B, K, d = 8, 128, 64
-        opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
+        opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn="self", mem="MoCo", nce_k=K, nce_t=0.15, alpha=0.99,
                                  cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
                                  batch_size=B, rank=0, world_size=1, s_dim=64, t_dim=64, moma_prec="bf16", queue_dtype="bf16",
                                  moma_fused=True, trace=[], overlap_teacher=True, graph_student=graph_student)
