@@ -95,8 +95,10 @@ def test_step_graphs_equal_the_eager_loop(model, overlap, prec, queue_dtype, amp
     assert a["index"] == b["index"] and a["index"][-1] == (14 * B + B - 3) % K
     assert a["next_perm"] == b["next_perm"]
     assert a["atts_k_grad_none"] and b["atts_k_grad_none"] and a["grads_attached"]
-    # (MIOpen's weight-gradient kernels are not bitwise reproducible run to run: last-bit differences grow over 15 steps)
-    tol = 2e-4 if amp is None else 5e-3
+    # (MIOpen's weight-gradient kernels are not bitwise reproducible run to run: last-bit differences grow over 15 steps -- the
+    #  eager loop against itself parts by up to 4.4e-4 in the losses over six repetitions of these cases, scripts/diag_graph_noise.py;
+    #  until round 6 the bound here was 2e-4 (+ 2e-4 relative): inside the noise on a bad day)
+    tol = 1e-3 if amp is None else 5e-3
     np.testing.assert_allclose(a["loss"], b["loss"], rtol=tol, atol=tol)
     np.testing.assert_allclose(a["loss_kd"], b["loss_kd"], rtol=tol, atol=tol)
     assert a["loss"][0] == b["loss"][0]
