@@ -165,7 +165,13 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
             // ---- partial scores over the wave's slab, segment by segment
             // (measured at one segment and not taken: the next tile's 16 pieces issued one per group of four score MFMAs instead of
             //  up front -- 389 vs 377 us with dq, 233 vs 210 forward-only; the pieces by inline asm with one base + one xor each
-            //  instead of the builtin's ~12 instructions -- 384 / 212 us, no change: the DMA issue is not what the tile waits for)
+            //  instead of the builtin's ~12 instructions -- 384 / 212 us, no change: the DMA issue is not what the tile waits for;
+            //  round 6, ablation builds (scripts/build_k2_f32_variants.py; call = kernel + 12 us combine, d = 512, same box): 388 us as
+            //  shipped, 358 without the exchange's two barriers (354 without the whole exchange, 396 without the second barrier
+            //  alone: what they cost is the skew of the four waves, and one barrier pays all of it), 388 without the exponentials,
+            //  354 without the refill, 390 without its vmcnt waits, 320 with none of the three = the two MFMA loops and their LDS
+            //  reads alone; the pieces one per MFMA behind the first quarter of the score product: 387 vs 390, 227 vs 231 at
+            //  d = 256, 140 vs 143 at d = 128 -- not taken for 1-2 %)
             f32x16 x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = 0.f;
@@ -213,6 +219,9 @@ __global__ __launch_bounds__(256) void infonce_f32_flash_kernel(const float* __r
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                   // xs is free for the next tile
             // ---- softmax against the fixed reference (register r of lane half h is key (r&3) + 8 (r>>2) + 4 h)
+            // (measured in round 6 and not taken: each numerator formed one k-step ahead of its use, in the shadow of P.K's 64-cycle
+            //  MFMAs -- register s is the A operand of k-step s -- instead of all 16 up front: 400 vs 400 us per call at d = 512,
+            //  230 vs 234 at d = 256, same box, three alternating runs: these 48 VALU instructions are not what the tile waits for)
             if ((t + 1) * KT > K) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
