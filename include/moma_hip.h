@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOMA_ABI_VERSION 3
+#define MOMA_ABI_VERSION 4
 
 enum { MOMA_PREC_F32 = 0, MOMA_PREC_BF16 = 1 };
 enum { MOMA_DT_F32 = 0, MOMA_DT_BF16 = 1 };
@@ -101,6 +101,10 @@ int moma_queue_prefetch(const void* queue, size_t bytes, moma_stream_t stream);
  *     out[b,0] = <q_b,k_b>*inv_T ; out[b,1+j] = <queue_j,q_b>*inv_T ; out is [B,K+1] fp32 contiguous.
  * moma_infonce_logits_bwd -- the autograd backward of the above w.r.t. q:
  *     dq[b,:] = (dlogits[b,0]*k_b + sum_j dlogits[b,1+j]*queue_j) * inv_T          (dq is [B,d] fp32)
+ *     The contraction over K is split over workgroups.  moma_infonce_logits_bwd_ws (round 6) keeps one partial product per split
+ *     in a caller-owned workspace (moma_infonce_logits_bwd_workspace_bytes()) and adds them in split order: bitwise reproducible,
+ *     like every other result of this library.  moma_infonce_logits_bwd, the form without a workspace, lets the splits meet in
+ *     fp32 atomics: equal up to the order of the additions (last bits differ from run to run).
  * moma_infonce_fused -- replaces the whole chain MoCo.forward (MoMA/mem_moco.py:77-100, minus the
  *     enqueue) + nn.CrossEntropyLoss(logits, 0) + top-1 accuracy (helper/loops_moma.py:322,331-335,
  *     learning/contrast_trainer.py:189-205) and its backward, in one pass over the queue:
@@ -117,6 +121,10 @@ int moma_infonce_logits(const float* q, const float* k, const void* queue, float
 int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* queue, float* dq,
                             int B, int d, int K, float inv_T, int qdtype, int prec,
                             moma_stream_t stream);
+size_t moma_infonce_logits_bwd_workspace_bytes(int B, int d, int K);
+int moma_infonce_logits_bwd_ws(const float* dlogits, const float* k, const void* queue, float* dq,
+                               int B, int d, int K, float inv_T, int qdtype, int prec,
+                               void* workspace, size_t workspace_bytes, moma_stream_t stream);
 /* gradients of the logits w.r.t. the key / queue operands (needed by the MoCoAtt cross-attention variants,
  * MoMA/mem_moco.py:103-161, where k and the queue are attention outputs that carry gradient):
  *     dk[b,:]     = dlogits[b,0] * q_b * inv_T                          (may be NULL)

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MOMA_HIP_LIB", os.path.join(_HERE, "lib", "libmoma_hi
 PREC_F32, PREC_BF16 = 0, 1
 DT_F32, DT_BF16 = 0, 1
 MHA_SAVE_PROBS, MHA_SAVE_LSE = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 EMA_BLOCK_ELEMS = 4096
 
 _p = C.c_void_p
@@ -34,6 +34,8 @@ SIGNATURES = {
     "moma_queue_prefetch": (_i, [_p, _z, _p]),
     "moma_infonce_logits": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
     "moma_infonce_logits_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p]),
+    "moma_infonce_logits_bwd_workspace_bytes": (_z, [_i, _i, _i]),
+    "moma_infonce_logits_bwd_ws": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _p, _z, _p]),
     "moma_infonce_logits_bwd_kq": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "moma_infonce_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "moma_infonce_fused": (_i, [_p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _z, _i, _i, _p]),

@@ -22,7 +22,7 @@ GemmArgs gemm(const float* A, const void* B, float* C, int M, int N, int K, long
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = g.strideB = g.strideC = 0; g.batch = 1;
-    g.transA = tA; g.transB = tB; g.alpha = alpha; g.splitk = 1; g.atomic = 0;
+    g.transA = tA; g.transB = tB; g.alpha = alpha; g.splitk = 1; g.atomic = 0; g.splitC = 0;
     g.b_dtype = MOMA_DT_F32; g.prec = prec;
     return g;
 }
@@ -94,25 +94,60 @@ int moma_infonce_logits(const float* q, const float* k, const void* queue, float
     return hip_rc(launch_gemm(g, st));
 }
 
+// dq = dlogits[:,0] k inv_T + dlogits[:,1:] . queue inv_T: the contraction over K is split over workgroups (B x d is a handful of
+// output tiles).  With `parts` (splitk x B x d floats) every split writes its own partial product and a last launch adds them in
+// split order -- bitwise reproducible; without it the splits meet in fp32 atomics (equal up to the order of the additions).
+static int logits_bwd_splitk(int B, int d, int K) {
+    const int tiles = ((B + 63) / 64) * ((d + 63) / 64);
+    int splitk = (1024 + tiles - 1) / tiles;
+    const int ktiles = (K + 31) / 32;
+    if (splitk > ktiles) splitk = ktiles;
+    return splitk < 1 ? 1 : splitk;
+}
+static size_t logits_bwd_parts_bytes(int B, int d, int K) {
+    const int sk = logits_bwd_splitk(B, d, K);
+    return sk > 1 ? align_up((size_t)sk * B * d * sizeof(float), 256) : 0;
+}
+static int logits_bwd_impl(const float* dlogits, const float* k, const void* queue, float* dq, int B, int d, int K, float inv_T,
+                           int qdtype, int prec, hipStream_t st, float* parts) {
+    const long ld = (long)K + 1;
+    MOMA_TRY(launch_pos_grad_init(dlogits, ld, k, dq, B, d, inv_T, st));
+    GemmArgs g = gemm(dlogits + 1, queue, dq, B, d, K, ld, d, d, 0, 1, inv_T, prec);
+    g.b_dtype = qdtype;
+    g.splitk = logits_bwd_splitk(B, d, K);
+    if (parts != nullptr && g.splitk > 1) {
+        g.C = parts;
+        g.splitC = (long)B * d;
+        MOMA_TRY(launch_gemm(g, st));
+        return hip_rc(launch_add_partials(dq, parts, g.splitk, (long)B * d, (long)B * d, st));
+    }
+    g.atomic = 1;                     // (also splitk == 1: one split adds its product to the initialised dq)
+    return hip_rc(launch_gemm(g, st));
+}
+
 int moma_infonce_logits_bwd(const float* dlogits, const float* k, const void* queue, float* dq, int B, int d,
                             int K, float inv_T, int qdtype, int prec, moma_stream_t stream) {
     if (!dlogits || !k || !queue || !dq) return MOMA_E_NULL;
     if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
     if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
-    hipStream_t st = (hipStream_t)stream;
-    const long ld = (long)K + 1;
-    MOMA_TRY(launch_pos_grad_init(dlogits, ld, k, dq, B, d, inv_T, st));
-    // dq += dlogits[:,1:] . queue   (contraction over K, split and combined with fp32 atomics)
-    GemmArgs g = gemm(dlogits + 1, queue, dq, B, d, K, ld, d, d, 0, 1, inv_T, prec);
-    g.b_dtype = qdtype;
-    const int tiles = ((B + 63) / 64) * ((d + 63) / 64);
-    int splitk = (1024 + tiles - 1) / tiles;
-    const int ktiles = (K + 31) / 32;
-    if (splitk > ktiles) splitk = ktiles;
-    if (splitk < 1) splitk = 1;
-    g.splitk = splitk;
-    g.atomic = 1;
-    return hip_rc(launch_gemm(g, st));
+    return logits_bwd_impl(dlogits, k, queue, dq, B, d, K, inv_T, qdtype, prec, (hipStream_t)stream, nullptr);
+}
+
+size_t moma_infonce_logits_bwd_workspace_bytes(int B, int d, int K) {
+    if (B <= 0 || d <= 0 || K <= 0) return 0;
+    const size_t b = logits_bwd_parts_bytes(B, d, K);
+    return b ? b : 256;               // (never 0 for a valid shape: 0 is the error value of the *_bytes functions)
+}
+
+int moma_infonce_logits_bwd_ws(const float* dlogits, const float* k, const void* queue, float* dq, int B, int d, int K,
+                               float inv_T, int qdtype, int prec, void* workspace, size_t workspace_bytes,
+                               moma_stream_t stream) {
+    if (!dlogits || !k || !queue || !dq || !workspace) return MOMA_E_NULL;
+    if (B <= 0 || d <= 0 || K <= 0) return MOMA_E_SHAPE;
+    if (bad_dt(qdtype) || bad_prec(prec)) return MOMA_E_DTYPE;
+    if (workspace_bytes < moma_infonce_logits_bwd_workspace_bytes(B, d, K)) return MOMA_E_WORKSPACE;
+    if (misaligned(workspace, 16)) return MOMA_E_ALIGN;
+    return logits_bwd_impl(dlogits, k, queue, dq, B, d, K, inv_T, qdtype, prec, (hipStream_t)stream, (float*)workspace);
 }
 
 int moma_infonce_logits_bwd_kq(const float* dlogits, const float* q, float* dk, float* dqueue, int B, int d, int K,
@@ -144,7 +179,7 @@ size_t moma_infonce_fused_workspace_bytes(int B, int d, int K, int qdtype, int p
     if (infonce_f32_flash_supported(B, d, K, qdtype, prec)) return infonce_f32_flash_workspace_bytes(B, d, K);
     if (f32_policy_widens_queue(B, d, K, qdtype, prec))
         return align_up((size_t)K * d * sizeof(float), 256) + infonce_f32_flash_workspace_bytes(B, d, K);
-    return align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256);
+    return align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256) + logits_bwd_parts_bytes(B, d, K);     // logits | split-K partials of dq
 }
 
 int moma_infonce_fused(const float* q, const float* k, const void* queue, int B, int d, int K, float inv_T,
@@ -211,7 +246,10 @@ static int fused_impl(const float* q, const void* q_packed, const float* k, cons
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, st);
     if (rc != MOMA_OK) return rc;
     MOMA_TRY(launch_infonce_rows(logits, B, K + 1, loss_rows, lse, top1, dq != nullptr, st));
-    if (dq) rc = moma_infonce_logits_bwd(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, stream);
+    if (dq) {
+        float* parts = (float*)((char*)workspace + align_up((size_t)B * ((size_t)K + 1) * sizeof(float), 256));
+        rc = logits_bwd_impl(logits, k, queue, dq, B, d, K, inv_T, qdtype, prec, st, logits_bwd_parts_bytes(B, d, K) ? parts : nullptr);
+    }
     if (ev_call_end) (void)hipEventRecord((hipEvent_t)ev_call_end, st);
     return rc;
 }

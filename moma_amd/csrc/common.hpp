@@ -96,6 +96,7 @@ struct GemmArgs {
     float alpha;
     int splitk;          // >= 1
     int atomic;          // 1: atomicAdd into C
+    long splitC;         // splitk > 1 without atomics: split s writes its partial product to C + s * splitC (the caller sums them)
     int b_dtype;         // MOMA_DT_*
     int prec;            // MOMA_PREC_*
     float* colsum_a;     // nullable: also write sum_k A(m,k) for every m (the bias gradient next to dW = dY^T X); only honoured
@@ -111,6 +112,8 @@ hipError_t launch_colsum(const float* x, float* out, int rows, int cols, long ld
 hipError_t launch_pos_logit(const float* q, const float* k, float* out, long ld_out, int B, int d, float inv_T, hipStream_t st);
 hipError_t launch_infonce_rows(float* logits, int B, int ncols, float* loss_rows, float* lse, int32_t* top1,
                                int write_probs, hipStream_t st);
+// dst[i] = ((dst[i] + parts[i]) + parts[stride + i]) + ... over nparts partial arrays: the fixed-order end of a split-K product
+hipError_t launch_add_partials(float* dst, const float* parts, int nparts, long n, long stride, hipStream_t st);
 hipError_t launch_pos_grad_init(const float* dlogits, long ld, const float* k, float* dq, int B, int d, float inv_T,
                                 hipStream_t st);
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int batch = blockIdx.z / g.splitk, split = blockIdx.z % g.splitk;
     const float* A = g.A + (long)batch * g.strideA;
     const TB* B = reinterpret_cast<const TB*>(g.B) + (long)batch * g.strideB;
-    float* C = g.C + (long)batch * g.strideC;
+    float* C = g.C + (long)batch * g.strideC + (g.atomic ? 0L : (long)split * g.splitC);
 
     const int ktiles = (g.K + BK - 1) / BK;
     const int per = (ktiles + g.splitk - 1) / g.splitk;

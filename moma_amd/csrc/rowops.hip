@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void pos_grad_init_kernel(const float* __restr
     const int b = (int)(i / d);
     dq[i] = dlogits[(long)b * ld] * k[i] * inv_T;
 }
+
+// dst += the partial products of a split-K GEMM, in split order (bitwise reproducible where atomics are not)
+__global__ __launch_bounds__(256) void add_partials_kernel(float* __restrict__ dst, const float* __restrict__ parts, int nparts, long n,
+                                                            long stride) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = dst[i];
+    for (int s = 0; s < nparts; ++s) v += parts[(long)s * stride + i];
+    dst[i] = v;
+}
 }  // namespace
 
 hipError_t launch_softmax_rows(float* s, long rows, int cols, hipStream_t st) {
@@ -168,6 +178,11 @@ hipError_t launch_pos_logit(const float* q, const float* k, float* out, long ld_
 hipError_t launch_infonce_rows(float* logits, int B, int ncols, float* loss_rows, float* lse, int32_t* top1,
                                int write_probs, hipStream_t st) {
     hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), 0, st, logits, ncols, loss_rows, lse, top1, write_probs);
+    return hipGetLastError();
+}
+hipError_t launch_add_partials(float* dst, const float* parts, int nparts, long n, long stride, hipStream_t st) {
+    if (n <= 0 || nparts <= 0) return hipSuccess;
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, parts, nparts, n, stride);
     return hipGetLastError();
 }
 hipError_t launch_pos_grad_init(const float* dlogits, long ld, const float* k, float* dq, int B, int d, float inv_T,

@@ -249,9 +249,11 @@ class _InfoNCELogits(torch.autograd.Function):
         dq = dk = dqueue = None
         if ctx.needs_input_grad[0]:
             dq = torch.empty(B, d, device=k.device, dtype=torch.float32)
-            check(lib.moma_infonce_logits_bwd(_ptr(dlogits), _ptr(k), _ptr(queue), _ptr(dq), B, d, K,
-                                              float(1.0 / ctx.T), _qdtype(queue), ctx.prec, _stream()),
-                  "moma_infonce_logits_bwd")
+            # (the form with a workspace: the split-K partials are added in a fixed order -- bitwise reproducible)
+            ws = torch.empty(lib.moma_infonce_logits_bwd_workspace_bytes(B, d, K), device=k.device, dtype=torch.uint8)
+            check(lib.moma_infonce_logits_bwd_ws(_ptr(dlogits), _ptr(k), _ptr(queue), _ptr(dq), B, d, K,
+                                                 float(1.0 / ctx.T), _qdtype(queue), ctx.prec, _ptr(ws), ws.numel(), _stream()),
+                  "moma_infonce_logits_bwd_ws")
         # k / queue carry gradient only in the MoCoAtt cross-attention variants (they are attention outputs there)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if ctx.needs_input_grad[1]:

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-from test_gpu_step_graph import _run
+from test_gpu_step_graph import _run_impl as _run       # (the searched, non-deterministic MIOpen algorithms: the noise this script measures)
 
 for attn, mem, prec, qd in (("self_nomix", "MoCo", "bf16", "bf16"), ("self_mix", "MoCo", "bf16", "bf16"), ("all", "MoCoAtt", "bf16", "fp32"),
                             ("dual", "MoCoAtt", "fp32", "fp32"), ("self", "MoCo", "bf16", "bf16")):

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in _declared():
         assert hasattr(lib, name), name
     lib.moma_version.restype = ctypes.c_int
-    assert lib.moma_version() == 3
+    assert lib.moma_version() == 4
     lib.moma_error_string.restype = ctypes.c_char_p
     assert lib.moma_error_string(-2)
 

@@ -435,6 +435,35 @@ def test_infonce_fused_bitwise_repeatable(ops):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,d,K,prec,qdt", [(256, 512, 16384, "fp32", "fp32"), (256, 512, 16384, "bf16", "bf16"), (8, 64, 256, "fp32", "fp32"),
+                                            (100, 96, 5000, "fp32", "bf16"), (64, 1536, 4096, "fp32", "fp32")])
+def test_materialised_logits_paths_are_bitwise_repeatable(ops, B, d, K, prec, qdt):
+    """The gradient product of the materialised-logits paths -- `infonce_logits` (the reference's call sequence, MoMA/mem_moco.py:29-49,
+    used by the MoCoAtt variants) and the staged form of `infonce_fused` (exact fp32 at widths without a one-pass kernel) -- splits
+    its contraction over K across workgroups.  Until round 6 the splits met in fp32 atomics (last bits changed from run to run --
+    found as the one loop configuration whose eager runs were not bit-identical under MIOpen's deterministic algorithms); now each
+    split leaves a partial in the workspace and they are added in split order."""
+    rng = np.random.default_rng(B + d + K)
+    q = (rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    k = (q + 0.3 * rng.standard_normal((B, d)) / np.sqrt(d)).astype(np.float32)
+    queue = _t(O.l2_normalize(rng.standard_normal((K, d)).astype(np.float32)), torch.bfloat16 if qdt == "bf16" else torch.float32)
+    w = _t(rng.standard_normal((B, K + 1)).astype(np.float32))
+    grads, fused = [], []
+    for _ in range(3):
+        tq = _t(q).requires_grad_(True)
+        (ops.infonce_logits(tq, _t(k), queue, 0.15, prec) * w).sum().backward()
+        grads.append(tq.grad.clone())
+        tq = _t(q).requires_grad_(True)
+        lr, lse, _ = ops.infonce_fused(tq, _t(k), queue, 0.15, prec)
+        lr.sum().backward()
+        fused.append((lr.detach().clone(), tq.grad.clone()))
+    assert all(torch.equal(grads[0], g) for g in grads[1:])
+    assert all(torch.equal(fused[0][0], f[0]) and torch.equal(fused[0][1], f[1]) for f in fused[1:])
+    ref = (w.double()[:, :1] * _t(k).double() + w.double()[:, 1:] @ queue.double()) / 0.15
+    tol = 2e-5 if prec == "fp32" else 2e-2
+    assert (grads[0].double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ K1
 @pytest.mark.parametrize("prec,rtol,atol", [("fp32", 2e-4, 2e-5), ("bf16", 5e-2, 2e-2)])
 def test_mha_golden(ops, golden_dir, prec, rtol, atol):
@@ -766,7 +795,7 @@ def test_abi_argument_checks(ops):
     from moma_amd import _lib
     import ctypes as C
     lib = _lib.load()
-    assert lib.moma_version() == _lib.ABI_VERSION == 3
+    assert lib.moma_version() == _lib.ABI_VERSION == 4
     q = torch.zeros(4, 8, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.moma_enqueue(None, C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 0, st) == -1
