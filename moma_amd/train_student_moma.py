@@ -11,7 +11,12 @@ and launch lines carry over.  What differs:
     reference, `--multiprocessing-distributed` + mp.spawn; the backend string 'nccl' is RCCL on ROCm;
   * new optional flags: --moma_prec, --queue_dtype, --amp, --channels_last, --shuffle_bn, --no_fused,
     --steps_per_epoch, --num_heads, --no_graph_teacher, --no_graph_student, --dp (student wrap at world size > 1: flat = one gradient all-reduce per step, the
-    default; ddp = stock DistributedDataParallel as in the reference).
+    default; ddp = stock DistributedDataParallel as in the reference);
+  * the reference's default run is cudnn.deterministic (a seed is set: :241-246; cudnn.benchmark only with its --deterministic
+    switch, :417-418).  MIOpen's deterministic algorithms cost 3.9x at BASELINE configs[1] (158 vs 40 ms per step), so here that
+    mode is opt-in: `--reproducible` (seeded, deterministic algorithms, no find mode).  This library adds nothing unordered (no
+    atomics): inside one process the loop then repeats bit for bit (tests/test_gpu_step_graph.py); between processes MIOpen's own
+    solver choice can still differ (scripts/diag_cli_trace.py).  The default is MIOpen's fast algorithms.
 """
 from __future__ import print_function
 
@@ -122,6 +127,9 @@ def build_parser():
     p.add_argument("--no_graph_student", dest="graph_student", action="store_false",
                    help="issue the student forward / backward (and the teacher side, K1, K4) launch by launch instead of replaying "
                         "the step from HIP graphs (helper/step_graph.py)")
+    p.add_argument("--reproducible", action="store_true",
+                   help="the reference's default semantics (cudnn.deterministic with the seed, no benchmark mode): MIOpen's "
+                        "deterministic algorithms, at 3.9x the step time of the default on EfficientNet-B0")
     p.add_argument("--miopen_find", default="on", choices=["on", "off"],
                    help="on = cudnn.benchmark as in the reference (MIOpen find mode: minutes at the first step of a new "
                         "shape); off = immediate mode with the shipped find-db")
@@ -305,7 +313,18 @@ def main_worker(gpu, ngpus_per_node, opt):
         random.seed(opt.seed)
         torch.manual_seed(opt.seed)
         np.random.seed(opt.seed)
-    torch.backends.cudnn.benchmark = opt.miopen_find == "on"          # reference :418 sets it unconditionally
+    # (reference: benchmark on in init_ddp_environment (:34), off again + cudnn.deterministic with a seed (:241-246), on only with
+    #  its --deterministic switch (:417-418); here the fast algorithms are the default and --reproducible asks for that mode)
+    if getattr(opt, "reproducible", False):
+        if opt.seed is None:
+            opt.seed = 12345
+            random.seed(opt.seed); torch.manual_seed(opt.seed); np.random.seed(opt.seed)
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
+        print("reproducible: MIOpen deterministic algorithms, seed {} (bitwise repeatable inside a process; MIOpen's solver choice "
+              "may differ between processes)".format(opt.seed))
+    else:
+        torch.backends.cudnn.benchmark = opt.miopen_find == "on"
     device = torch.device("cuda", opt.gpu) if torch.cuda.is_available() else torch.device("cpu")
     opt.device = device
     print("opt.n_cls: ", opt.n_cls)

@@ -71,6 +71,27 @@ def test_cli_resume_continues_queue_pointer(tmp_path, amp):
         assert state.get("grad_scaler") is None
 
 
+def test_cli_reproducible_mode_trains(tmp_path):
+    """`--reproducible` = the reference's default semantics (a seed + cudnn.deterministic, train_student_moma.py:241-246): MIOpen's
+    deterministic algorithms and no find mode.  What it buys is measured elsewhere (tests/test_gpu_step_graph.py: inside one process
+    the loop repeats bit for bit -- nothing in this library adds in an unordered way; ACROSS processes MIOpen's own solver choice
+    can still differ: scripts/diag_cli_trace.py saw 2-3 distinct traces over 5 processes, parting at the second step, graphs on or
+    off); here: the mode is accepted, trains with the step served from graphs, and says what it is."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "train_student_moma.py"), "--distill", "moma", "--model_s", "resnet8x4",
+           "--model_t", "resnet8x4", "--dataset", "cifar100", "--n_cls", "2", "--batch_size", "32", "--epochs", "2",
+           "--steps_per_epoch", "7", "--nce_k", "1024", "--head", "mlp", "--feat_dim", "128", "-c", "1", "-d", "1", "-b", "1",
+           "--reproducible", "--save_root", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "reproducible: MIOpen deterministic algorithms" in r.stdout and "best accuracy" in r.stdout
+    ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f == "ckpt_last.pth"]
+    state = torch.load(ck[0], map_location="cpu", weights_only=False)
+    assert state["epoch"] == 2 and state["contrast"]["_extra_state"]["index"] == (14 * 32) % 1024
+    assert all(torch.isfinite(v).all() for v in state["model"].values() if v.is_floating_point())
+
+
 def test_cli_reference_launch_mode_spawns_one_rccl_rank_and_resumes(tmp_path):
     """The reference's OWN launch mode for `--distill moma` (train_student_moma.py:207-224: --multiprocessing-distributed, mp.spawn,
     one process per GPU, backend 'nccl' = RCCL): on the one GPU of the box that is ONE spawned rank on a real RCCL communicator

@@ -464,6 +464,19 @@ def test_materialised_logits_paths_are_bitwise_repeatable(ops, B, d, K, prec, qd
     assert (grads[0].double() - ref).abs().max().item() <= tol * ref.abs().max().item()
 
 
+def test_kernels_give_the_same_bits_in_every_process():
+    """K1 forward + backward, K2 (one-pass, wide rows, staged, the logits path), K3, in both policies, on seeded inputs, in separate
+    PROCESSES with different allocation histories: one digest.  (No atomics, no result that depends on what a workspace held before:
+    the run-to-run differences of whole training runs between processes come from the stock backbone's MIOpen solver choice,
+    scripts/diag_cli_trace.py.)"""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "diag_kernels_across_processes.py")
+    r = subprocess.run([sys.executable, script, "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "3 processes, 1 distinct digests" in r.stdout, r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ K1
 @pytest.mark.parametrize("prec,rtol,atol", [("fp32", 2e-4, 2e-5), ("bf16", 5e-2, 2e-2)])
 def test_mha_golden(ops, golden_dir, prec, rtol, atol):

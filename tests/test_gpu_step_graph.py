@@ -37,7 +37,7 @@ def _same(a, b):
 
 
 def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16,
-              attn="self", mem="MoCo"):
+              attn="self", mem="MoCo", data_on_device=False):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -77,6 +77,8 @@ def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, s
     gen = torch.Generator().manual_seed(3)
     data = [(torch.randn(B, 3, size, size, generator=gen), torch.randint(0, 10, (B,), generator=gen)) for _ in range(epochs * steps)]
     data.append((torch.randn(B - 3, 3, size, size, generator=gen), torch.randint(0, 10, (B - 3,), generator=gen)))   # ragged last batch
+    if data_on_device:          # (as the CLI's synthetic loader hands them over: no host-blocking copy in the step, the host runs ahead)
+        data = [(x.to(dev), y.to(dev)) for x, y in data]
     torch.manual_seed(99)                                              # the Shuffle-BN permutation stream (host generator)
     for ep in range(epochs):
         loader = data[ep * steps:(ep + 1) * steps] + ([data[-1]] if ep == epochs - 1 else [])
@@ -117,6 +119,21 @@ def test_step_graphs_equal_the_eager_loop(model, overlap, prec, queue_dtype, amp
     assert a["atts_k_grad_none"] and b["atts_k_grad_none"] and a["grads_attached"]
     _same(a, b)
     assert all(a["student"][name] == 15 for name in a["student"] if "num_batches_tracked" in name)
+
+
+@pytest.mark.parametrize("prec,queue_dtype", [("bf16", "bf16"), ("fp32", "fp32")])
+def test_the_eager_loop_repeats_bit_for_bit(prec, queue_dtype):
+    """The premise of the exact comparisons in this file: under MIOpen's deterministic algorithms two runs of the loop in one process
+    are bit-identical (no atomics anywhere in this library since round 6; fp32 at d = 64 takes the staged K2 path whose split-K
+    gradient used them), with the batches resident on the device as the CLI's loader hands them over (the host runs ahead)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(False, "resnet8", True, prec, queue_dtype, None, data_on_device=True)
+    b = _run(False, "resnet8", True, prec, queue_dtype, None, data_on_device=True)
+    c = _run(True, "resnet8", True, prec, queue_dtype, None, data_on_device=True)
+    _same(a, b)
+    _same(c, b)
+    assert c["replays"] == 9 and a["index"] == b["index"] == c["index"]
 
 
 @pytest.mark.parametrize("attn", ["self_mix", "self_nomix"])
