@@ -3,7 +3,9 @@ allocates for a call is carved out of a larger buffer filled with a canary patte
 the call the canaries must be untouched.  (GPU AddressSanitizer is not available on this pool; a kernel that stores its padded
 rows -- B rounded up to 32 / 128, K to the tile, d to the segment -- past the end of a [B, d] result would corrupt whatever the
 allocator placed next and no parity test would see it.)  The caller-owned targets of the in-place entry points (queue, EMA
-tensors) get the same treatment."""
+tensors) get the same treatment.  The canary byte is 0xFF -- NaN as fp32 and as bf16 -- and the INPUTS sit in guarded buffers too:
+a result that depended on a read past the end of an operand (a tail row, a tail key, a tail column) would come out NaN, and
+every result is compared bit for bit with the same call on ordinary allocations."""
 import math
 
 import numpy as np
@@ -12,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GUARD = 4096
-CANARY = 0xA5
+CANARY = 0xFF
 
 
 class _Guarded:
@@ -79,6 +81,13 @@ def _rand(rng, *shape, scale=1.0):
     return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32)).cuda()
 
 
+def _in(guard, t):
+    """a copy of operand t between NaN guards (not recorded for the write check of the NEXT call: inputs are re-checked with it)"""
+    g = guard.empty(*t.shape, device="cuda", dtype=t.dtype)
+    g.copy_(t)
+    return g
+
+
 def test_the_guard_sees_an_overrun(guard):
     """the harness itself: one byte behind / in front of a guarded buffer is reported"""
     x = guard.empty(5, 3, device="cuda")
@@ -102,50 +111,62 @@ def test_the_guard_sees_an_overrun(guard):
                                         (64, 512, 16384, "bf16"), (65, 384, 5000, "fp32"), (50, 1280, 1500, "bf16"), (256, 1280, 8192, "bf16"),
                                         (37, 2048, 3001, "bf16"), (7, 96, 333, "fp32"), (129, 768, 2049, "fp32"), (31, 1536, 1000, "fp32"),
                                         (200, 640, 9000, "bf16"), (5, 64, 31, "fp32")])
-def test_k2_writes_stay_inside(guard, prec, B, d, K, qdt):
+def test_k2_writes_stay_inside(guard, prec, B, d, K, qdt, monkeypatch):
     """one-pass / small-batch / wide-row / exact-fp32 / staged K2, with and without dq, with the enqueue aboard, and the logits path"""
     from moma_amd import ops
     rng = np.random.default_rng(B * 7 + d + K)
-    q = _rand(rng, B, d, scale=1 / np.sqrt(d))
-    k = _rand(rng, B, d, scale=1 / np.sqrt(d))
+    q0 = _rand(rng, B, d, scale=1 / np.sqrt(d))
+    k0 = _rand(rng, B, d, scale=1 / np.sqrt(d))
     dt = torch.bfloat16 if qdt == "bf16" else torch.float32
-    queue = guard.empty(K, d, device="cuda", dtype=dt)
-    queue.copy_(torch.nn.functional.normalize(_rand(rng, K, d)).to(dt))
-    fwd = ops.infonce_fused(q, k, queue, 0.15, prec)
-    guard.check(f"K2 forward-only {prec} {(B, d, K, qdt)}")
-    tq = q.clone().requires_grad_(True)
-    keep = guard.empty(K, d, device="cuda", dtype=dt)          # (records were cleared: guard the queue again for the enqueue)
-    keep.copy_(queue)
+    queue0 = torch.nn.functional.normalize(_rand(rng, K, d)).to(dt)
+    w0 = _rand(rng, B, K + 1)
     n = min(B, K)
-    lr, lse, top1 = ops.infonce_fused(tq, k, keep, 0.15, prec, enq=(k[:n].contiguous(), (K - 3) % K, None))
-    lr.sum().backward()
-    guard.check(f"K2 with dq + enqueue {prec} {(B, d, K, qdt)}")
-    assert torch.allclose(fwd[0], lr.detach(), rtol=1e-3, atol=1e-3) and torch.isfinite(tq.grad).all()
-    tq = q.clone().requires_grad_(True)
-    w = _rand(rng, B, K + 1)
-    (ops.infonce_logits(tq, k, queue, 0.15, prec) * w).sum().backward()
-    guard.check(f"logits path {prec} {(B, d, K, qdt)}")
-    assert torch.isfinite(tq.grad).all()
+
+    def run(q, k, queue, w):
+        fwd = ops.infonce_fused(q, k, queue, 0.15, prec)
+        tq = q.clone().requires_grad_(True)
+        lr, lse, top1 = ops.infonce_fused(tq, k, queue, 0.15, prec, enq=(k[:n].contiguous(), (K - 3) % K, None))
+        lr.sum().backward()
+        t2 = q.clone().requires_grad_(True)
+        (ops.infonce_logits(t2, k, queue, 0.15, prec) * w).sum().backward()
+        return [fwd[0], fwd[1], fwd[2], lr.detach(), lse, top1, tq.grad, t2.grad, queue.clone()]
+
+    with monkeypatch.context() as m:
+        m.setattr(ops, "torch", torch)                       # ordinary allocations
+        ref = run(q0, k0, queue0.clone(), w0)
+    got = run(_in(guard, q0), _in(guard, k0), _in(guard, queue0), _in(guard, w0))
+    guard.check(f"K2 {prec} {(B, d, K, qdt)}")
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 @pytest.mark.parametrize("N,d,H", [(1, 64, 4), (33, 128, 8), (129, 256, 2), (256, 512, 4), (300, 512, 4), (1000, 512, 4), (77, 192, 4),
                                    (100, 1280, 4), (300, 1280, 4), (700, 1280, 4), (1024, 1280, 4), (64, 2048, 8), (40, 96, 3)])
-def test_k1_writes_stay_inside(guard, prec, N, d, H):
+def test_k1_writes_stay_inside(guard, prec, N, d, H, monkeypatch):
     """fast path (narrow / wide heads, 1-4 key tiles per wave, flash loop) and the staged exact-fp32 path, forward + backward"""
     from moma_amd import ops
     rng = np.random.default_rng(N + d + H)
-    x = _rand(rng, N, d, scale=1 / np.sqrt(d)).requires_grad_(True)
-    ws = [_rand(rng, *s, scale=1 / np.sqrt(d)).requires_grad_(True) for s in ((3 * d, d), (3 * d,), (d, d), (d,))]
-    y = ops.mha(x, *ws, H, prec)
-    guard.check(f"K1 forward {prec} {(N, d, H)}")
-    (y * _rand(rng, N, d)).sum().backward()
-    guard.check(f"K1 backward {prec} {(N, d, H)}")
-    assert torch.isfinite(x.grad).all() and all(torch.isfinite(w.grad).all() for w in ws)
-    with torch.no_grad():
-        outs = ops.mha_group([(x.detach(), ws[0].detach(), ws[1].detach(), ws[2].detach(), ws[3].detach(), None)] * 2, H, prec)
-    guard.check(f"K1 grouped forward {prec} {(N, d, H)}")
-    assert torch.equal(outs[0], outs[1])
+    x0 = _rand(rng, N, d, scale=1 / np.sqrt(d))
+    ws0 = [_rand(rng, *s, scale=1 / np.sqrt(d)) for s in ((3 * d, d), (3 * d,), (d, d), (d,))]
+    dy0 = _rand(rng, N, d)
+
+    def run(x, ws, dy):
+        x = x.requires_grad_(True)
+        ws = [w.requires_grad_(True) for w in ws]
+        y = ops.mha(x, *ws, H, prec)
+        (y * dy).sum().backward()
+        with torch.no_grad():
+            outs = ops.mha_group([(x.detach(), ws[0].detach(), ws[1].detach(), ws[2].detach(), ws[3].detach(), None)] * 2, H, prec)
+        return [y.detach(), x.grad] + [w.grad for w in ws] + list(outs)
+
+    with monkeypatch.context() as m:
+        m.setattr(ops, "torch", torch)
+        ref = run(x0.clone(), [w.clone() for w in ws0], dy0)
+    got = run(_in(guard, x0), [_in(guard, w) for w in ws0], _in(guard, dy0))
+    guard.check(f"K1 {prec} {(N, d, H)}")
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
 
 
 @pytest.mark.parametrize("K,d,n,index,qdt", [(1000, 36, 77, 990, "fp32"), (1000, 36, 77, 990, "bf16"), (64, 512, 256, 60, "bf16"), (4096, 1280, 256, 4000, "bf16"),
