@@ -169,6 +169,42 @@ def test_k1_writes_stay_inside(guard, prec, N, d, H, monkeypatch):
         assert torch.isfinite(b).all() and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,d,K", [(256, 512, 65536), (64, 512, 16384), (33, 256, 777), (100, 384, 4097), (1, 128, 40), (130, 512, 5000)])
+def test_the_step_path_writes_stay_inside(guard, B, d, K, monkeypatch):
+    """what the graph-served step does: atts_q writes q in K2's packed layout (QPack: pad rows up to 128), K2 runs into caller-owned
+    K2Buffers with the enqueue aboard (bf16 mirror of an fp32 queue included), the dual-queue terms go through ONE multi-term call"""
+    from moma_amd import ops
+    rng = np.random.default_rng(B + d + K)
+    H, T = 4, 0.15
+    x0 = _rand(rng, B, d, scale=1 / np.sqrt(d))
+    ws0 = [_rand(rng, *s, scale=1 / np.sqrt(d)) for s in ((3 * d, d), (3 * d,), (d, d), (d,))]
+    k0 = _rand(rng, B, d, scale=1 / np.sqrt(d))
+    q32_0 = torch.nn.functional.normalize(_rand(rng, K, d))
+    n = min(B, K)
+
+    def run(x, ws, k, q32):
+        mirror = ops.torch.empty(K, d, device="cuda", dtype=torch.bfloat16)
+        mirror.copy_(q32)
+        qp = ops.QPack().prepare(B, d, T, x.device)
+        with torch.no_grad():
+            q = ops.mha(x, *ws, H, "bf16", None, qp)
+        bufs = ops.K2Buffers(B, d, K, torch.bfloat16, "bf16", x.device)
+        use = qp.buf if (qp is not None and qp.matches(q, T)) else None
+        ops.infonce_fused_into(q, k, mirror, T, "bf16", use, bufs, enq=(k[:n].contiguous(), (K - 5) % K, q32))
+        terms = ops.infonce_fused_multi([(q, k, mirror), (k, q, mirror)], T, "bf16")
+        return [q, bufs.loss_rows, bufs.lse, bufs.top1, bufs.dq, mirror, q32] + [t for term in terms for t in term] + \
+            ([] if qp is None else [qp.buf])
+
+    with monkeypatch.context() as m:
+        m.setattr(ops, "torch", torch)
+        ref = run(x0.clone(), [w.clone() for w in ws0], k0.clone(), q32_0.clone())
+    got = run(_in(guard, x0), [_in(guard, w) for w in ws0], _in(guard, k0), _in(guard, q32_0))
+    guard.check(f"step path {(B, d, K)}")
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+    assert torch.equal(got[5], got[6].to(torch.bfloat16))          # the mirror is the bf16 image of the fp32 queue, enqueued rows included
+
+
 @pytest.mark.parametrize("K,d,n,index,qdt", [(1000, 36, 77, 990, "fp32"), (1000, 36, 77, 990, "bf16"), (64, 512, 256, 60, "bf16"), (4096, 1280, 256, 4000, "bf16"),
                                               (50, 24, 120, 49, "fp32"), (257, 130, 31, 256, "bf16")])
 def test_k3_k4_writes_stay_inside(guard, K, d, n, index, qdt):
