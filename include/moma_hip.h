@@ -43,7 +43,8 @@ enum {
     MOMA_E_NULL = -1,      /* a required pointer is NULL                        */
     MOMA_E_SHAPE = -2,     /* a dimension is <= 0 or inconsistent               */
     MOMA_E_DTYPE = -3,     /* unknown prec / qdtype                             */
-    MOMA_E_ALIGN = -4,     /* pointer not aligned to its element size           */
+    MOMA_E_ALIGN = -4,     /* pointer not aligned to its element size -- or, for the operands the fast paths move in 16-byte pieces (K1 fast
+                              path, one-pass K2: q, k, queue, dq), not to 16 bytes */
     MOMA_E_WORKSPACE = -5, /* workspace too small                               */
     MOMA_E_UNSUPPORTED = -6
 };

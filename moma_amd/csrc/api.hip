@@ -214,6 +214,13 @@ static int fused_impl(const float* q, const void* q_packed, const float* k, cons
     hipStream_t st = (hipStream_t)stream;
     if (q_packed && (misaligned(q_packed, 16) || infonce_qpack_bytes(B, d) == 0 || !infonce_flash_supported(B, d, K, qdtype, prec)))
         return q_packed && misaligned(q_packed, 16) ? MOMA_E_ALIGN : MOMA_E_UNSUPPORTED;
+    // the one-pass kernels move q / k / dq in 16-byte pieces and the queue by 16-byte LDS-DMA: operands that start inside a vector
+    // (an element-granular view of a larger buffer) are refused here instead of faulting there
+    const bool one_pass = infonce_flash_supported(B, d, K, qdtype, prec) || infonce_f32_flash_supported(B, d, K, qdtype, prec) ||
+                          f32_policy_widens_queue(B, d, K, qdtype, prec);
+    if (one_pass && (misaligned(q, 16) || misaligned(k, 16) || misaligned(queue, 16) || (dq && misaligned(dq, 16)))) return MOMA_E_ALIGN;
+    if (!one_pass && (misaligned(q, 4) || misaligned(k, 4) || misaligned(queue, qdtype == MOMA_DT_BF16 ? 2 : 4) || (dq && misaligned(dq, 4))))
+        return MOMA_E_ALIGN;
     if (infonce_flash_supported(B, d, K, qdtype, prec)) {
         if (carried) *carried = 1;
         return hip_rc(launch_infonce_flash(q, k, queue, B, d, K, inv_T, loss_rows, lse, top1, dq, workspace, qdtype, st,

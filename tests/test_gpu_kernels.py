@@ -816,6 +816,19 @@ def test_abi_argument_checks(ops):
     assert lib.moma_enqueue(C.c_void_p(q.data_ptr()), C.c_void_p(q.data_ptr()), 4, 0, 8, 8, 7, st) == -3
     assert lib.moma_mha_fwd(*([C.c_void_p(q.data_ptr())] * 9), 4, 8, 3, 0, st) == -2
     assert b"workspace" in lib.moma_error_string(-5)
+    # operands of the one-pass K2 kernels that start inside a 16-byte vector are refused (-4), not launched
+    B, d, K = 64, 512, 4096
+    big = torch.zeros(B * d + 8, device="cuda")
+    queue = torch.zeros(K, d, device="cuda", dtype=torch.bfloat16)
+    outs = [torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda", dtype=torch.int32)]
+    ws = torch.zeros(lib.moma_infonce_fused_workspace_bytes(B, d, K, 1, 1), device="cuda", dtype=torch.uint8)
+    ok_q = big[:B * d].view(B, d)
+    for off, want in ((0, 0), (1, -4), (2, -4), (4, 0)):
+        qv = big[off:off + B * d].view(B, d)
+        rc = lib.moma_infonce_fused(C.c_void_p(qv.data_ptr()), C.c_void_p(ok_q.data_ptr()), C.c_void_p(queue.data_ptr()), B, d, K, C.c_float(6.0),
+                                    *[C.c_void_p(o.data_ptr()) for o in outs], None, C.c_void_p(ws.data_ptr()), ws.numel(), 1, 1, st)
+        assert rc == want, (off, rc)
+    torch.cuda.synchronize()
     with pytest.raises(_lib.MomaHipError):
         ops.enqueue_(torch.zeros(4, 8), torch.zeros(2, 8), 0)      # CPU tensors are refused, no fallback
 
