@@ -110,7 +110,8 @@ def test_the_guard_sees_an_overrun(guard):
 @pytest.mark.parametrize("B,d,K,qdt", [(1, 128, 40, "bf16"), (33, 256, 777, "bf16"), (100, 512, 4097, "bf16"), (256, 512, 65536, "bf16"),
                                         (64, 512, 16384, "bf16"), (65, 384, 5000, "fp32"), (50, 1280, 1500, "bf16"), (256, 1280, 8192, "bf16"),
                                         (37, 2048, 3001, "bf16"), (7, 96, 333, "fp32"), (129, 768, 2049, "fp32"), (31, 1536, 1000, "fp32"),
-                                        (200, 640, 9000, "bf16"), (5, 64, 31, "fp32")])
+                                        (200, 640, 9000, "bf16"), (5, 64, 31, "fp32"), (513, 512, 4097, "bf16"), (1000, 256, 2100, "bf16"),
+                                        (700, 1280, 1500, "bf16"), (2050, 128, 1000, "fp32")])
 def test_k2_writes_stay_inside(guard, prec, B, d, K, qdt, monkeypatch):
     """one-pass / small-batch / wide-row / exact-fp32 / staged K2, with and without dq, with the enqueue aboard, and the logits path"""
     from moma_amd import ops

@@ -150,7 +150,9 @@ def test_infonce_golden(ops, golden_dir, prec, rtol, atol):
                                        (70, 1024, 3000, "bf16"), (257, 1536, 2500, "bf16"), (96, 768, 70001, "bf16"),
                                        (5, 1280, 17, "bf16"),
                                        # d = 2048 (ResNet-50 `--head None`): scores in two register passes of Q (8 + 8 segments)
-                                       (256, 2048, 8192, "bf16"), (130, 2048, 3001, "bf16"), (3, 2048, 40, "bf16")])
+                                       (256, 2048, 8192, "bf16"), (130, 2048, 3001, "bf16"), (3, 2048, 40, "bf16"),
+                                       # batches beyond 256 rows (more row blocks than the plans were tuned for: fewer, longer key chunks)
+                                       (512, 512, 8192, "bf16"), (1000, 256, 4100, "bf16"), (700, 1280, 3000, "bf16"), (2048, 128, 2048, "fp32")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_infonce_vs_oracle(ops, B, d, K, qdt, prec):
     rng = np.random.default_rng(B + d + K)
