@@ -36,7 +36,10 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "moma_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FILES = ["infonce_fused.hip", "infonce_f32.hip", "k1_fast.hip"]
+# the three hand-scheduled files (inline asm: checks a-d) and, for the spill budget (e) alone, the other kernel files of the KD path
+# (K3 / K4, the generic GEMM and the row kernels of the staged paths; the backbone helpers bn / dwconv / se can be named on the
+# command line: 600 more instantiations, all clean, a minute more)
+FILES = ["infonce_fused.hip", "infonce_f32.hip", "k1_fast.hip", "gemm.hip", "queue.hip", "rowops.hip"]
 SHOW = int(os.environ.get("AUDIT_SHOW", "3"))            # problems printed per kind and kernel
 
 # (e) kernels that may spill: demangled-name regex -> (max VGPR spills, max scratch bytes, max SGPR spills -- those go to the
@@ -47,6 +50,7 @@ ALLOW_SPILLS = {
     r"^k1_core_bwd_kernel<false>$": (1, 8, 6),               # (the same; head widths below 128: ViT-S, feat_dim 256)
     r"^infonce_f32_flash_kernel<2, 2, false>$": (0, 0, 2),   # forward-only exact-fp32 passes: scalar spills only
     r"^infonce_f32_flash_kernel<4, 4, false>$": (0, 0, 26),
+    r"^gemm_kernel<1, (unsigned short|float), false, false, 32>$": (0, 0, 2),   # generic GEMM (staged paths), unaligned operands
 }
 
 VM_RE = re.compile(r"^(global_|buffer_|scratch_|flat_)")
