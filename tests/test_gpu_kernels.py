@@ -670,6 +670,45 @@ def test_mha_fast_path_takes_bf16_input_and_follows_raw_pointer_weight_updates(o
     assert not torch.equal(before, after) and torch.equal(after, y32.detach())
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("N,d,H,qkv_bias", [(256, 512, 4, True), (100, 256, 4, False), (300, 1280, 4, True), (64, 384, 8, False)])
+def test_mha_partial_gradient_sets(ops, N, d, H, qkv_bias, prec):
+    """Backward with only SOME inputs wanting a gradient (a frozen attention module fed by a trainable encoder: dx alone; a bias
+    alone -- it rides on its weight gradient's launch --; everything but dx: the first module of a chain), with and without the
+    qkv bias (the reference's Attention has none: MoMA/criterion_moco_att.py:141-151): every gradient that is asked for equals the
+    one of the all-gradients run bit for bit, the others stay None."""
+    rng = np.random.default_rng(N + d)
+    x0 = O.l2_normalize(rng.standard_normal((N, d)).astype(np.float32))
+    bound = 1.0 / np.sqrt(d)
+    w0 = [rng.uniform(-bound, bound, shp).astype(np.float32) for shp in ((3 * d, d), (3 * d,), (d, d), (d,))]
+    dy = _t(rng.standard_normal((N, d)).astype(np.float32))
+
+    def run(mask):
+        ts = [_t(x0)] + [_t(a) for a in w0]
+        if not qkv_bias:
+            ts[2] = None
+        for t, m in zip(ts, mask):
+            if t is not None:
+                t.requires_grad_(bool(m))
+        y = ops.mha(*ts, H, prec)
+        if not any(m and t is not None for t, m in zip(ts, mask)):
+            assert not y.requires_grad
+            return y.detach(), [None] * 5
+        (y * dy).sum().backward()
+        return y.detach(), [None if t is None else t.grad for t in ts]
+
+    y_all, g_all = run([1, 1, 1, 1, 1])
+    for mask in ([1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1], [0, 1, 1, 1, 1], [1, 0, 1, 0, 1],
+                 [1, 1, 0, 1, 0], [0, 0, 0, 0, 0]):
+        y, g = run(mask)
+        assert torch.equal(y, y_all), mask
+        for i, (m, a, b) in enumerate(zip(mask, g, g_all)):
+            if m and b is not None:
+                assert a is not None and torch.equal(a, b), (mask, i)
+            else:
+                assert a is None, (mask, i)
+
+
 # ------------------------------------------------------------------------------------------------ ABI
 @pytest.mark.parametrize("N,d,H", [(256, 512, 4), (256, 1280, 4)])
 def test_mha_bitwise_repeatable_gradients(ops, N, d, H):
