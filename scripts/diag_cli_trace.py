@@ -13,17 +13,31 @@ if len(sys.argv) > 2 and sys.argv[1] == "--one":
     from moma_amd import train_student_moma as T
     opt = T.parse_option(args)
     opt.trace = []
-    T.main_worker(0, 1, opt)
+    import hashlib
     import torch
+    grads = []                                     # per optimizer step: (shape, digest of the gradient) of every parameter, in order
+    _step = torch.optim.SGD.step
+
+    def step(self, *a, **kw):
+        if len(grads) < 3:
+            grads.append([(tuple(p.shape), "none" if p.grad is None else hashlib.sha256(p.grad.detach().float().cpu().numpy().tobytes()).hexdigest()[:12])
+                          for g in self.param_groups for p in g["params"]])
+        return _step(self, *a, **kw)
+    torch.optim.SGD.step = step
+    T.main_worker(0, 1, opt)
     torch.cuda.synchronize()
     with open(out, "w") as f:
         for loss, index, loss_kd in opt.trace:
             f.write(f"{float(loss).hex()} {index} {float(loss_kd).hex()}\n")
+    with open(out + ".grads", "w") as f:
+        for i, g in enumerate(grads):
+            for j, (shape, dg) in enumerate(g):
+                f.write(f"{i} {j} {shape} {dg}\n")
     sys.exit(0)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 for label, extra in (("graphs on", []), ("--no_graph_teacher", ["--no_graph_teacher"]), ("--no_graph_student", ["--no_graph_student"])):
-    traces = []
+    traces, gradlogs = [], []
     with tempfile.TemporaryDirectory() as tmp:
         for r in range(N):
             out = os.path.join(tmp, f"t{r}.txt")
@@ -33,11 +47,20 @@ for label, extra in (("graphs on", []), ("--no_graph_teacher", ["--no_graph_teac
                 print(label, "FAILED", p.stderr[-800:], flush=True)
                 break
             traces.append(open(out).read().splitlines())
+            gradlogs.append(open(out + ".grads").read().splitlines())
     if len(traces) < N:
         continue
     firsts = []
     for t in traces[1:]:
         firsts.append(next((i for i, (a, b) in enumerate(zip(traces[0], t)) if a != b), None))
     print(f"{label}: {N} processes, {len(set(map(tuple, traces)))} distinct traces; first differing step vs run 0: {firsts}", flush=True)
-    for t in traces:
-        print("    ", " ".join(l.split()[0][-8:] for l in t[:14]), flush=True)
+    # the first gradient (optimizer step, parameter index, shape) that is not the same in every process
+    for row in zip(*gradlogs):
+        if len(set(row)) > 1:
+            step_i, j, rest = row[0].split(" ", 2)
+            n_params = sum(1 for l in gradlogs[0] if l.startswith("0 "))
+            differing = sorted({r.split(" ", 2)[1] for rows in zip(*gradlogs) if len(set(rows)) > 1 and rows[0].startswith(step_i + " ") for r in rows[:1]}, key=int)
+            print(f"    first differing gradient: optimizer step {step_i}, parameter {j} of {n_params}, {rest.rsplit(' ', 1)[0]}; parameters that differ in that step: {differing[:40]}", flush=True)
+            break
+    else:
+        print("    gradients of the first three steps: identical in every process", flush=True)
