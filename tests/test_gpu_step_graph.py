@@ -37,7 +37,7 @@ def _same(a, b):
 
 
 def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16,
-              attn="self", mem="MoCo", data_on_device=False):
+              attn="self", mem="MoCo", data_on_device=False, validate=False):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -83,6 +83,10 @@ def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, s
     for ep in range(epochs):
         loader = data[ep * steps:(ep + 1) * steps] + ([data[-1]] if ep == epochs - 1 else [])
         train_distill_moma(ep + 1, loader, mods, crits, trainer, contrast, optimizer, opt)
+        if validate:            # as the CLI does between two epochs: every module in eval mode, the student forward without autocast
+            from moma_amd.helper.loops_moma import validate_distill
+            opt.n_cls = 10
+            validate_distill(data[:2], mods, crits[0], opt, prefix="Val")
     torch.cuda.synchronize()
     sg = getattr(trainer, "_step_graphs", None)
     return dict(loss=torch.stack([t[0] for t in opt.trace]).cpu().numpy(), loss_kd=torch.stack([t[2] for t in opt.trace]).cpu().numpy(),
