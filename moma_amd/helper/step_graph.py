@@ -137,9 +137,26 @@ class StepGraphs:
                 float(st.opt.alpha), float(getattr(st.criterion_div, "T", 0.0)))
 
     # ---- one step ---------------------------------------------------------------------------------------------------------
+    def _switch(self, replayed: bool, device):
+        """The loop changes between replayed and eagerly issued steps (the step that opens an epoch, a ragged last batch, a variant
+        not captured yet): the device drains first.  Round 6: with the teacher side on its own stream and the host running ahead
+        (batches already on the device: nothing in the step blocks the host), an EAGER step issued behind replays still in flight
+        never finished -- the process sat in the epoch's closing read-back for good (scripts/diag_equivalences.py, HANG=1: the
+        second run of a process, EfficientNet pair, reproducible; not with one stream, not with a synchronisation in front of the
+        step).  Cause inside the runtime not established; a switch happens a few times per epoch, the drain costs nothing there."""
+        if getattr(self, "_replayed_last", None) not in (None, replayed):
+            torch.cuda.synchronize(device)
+        self._replayed_last = replayed
+
     def step(self, images, labels):
         if not self.enabled or not images.is_cuda:
             return None
+        res = self._step(images, labels)
+        if res is None:
+            self._switch(False, images.device)
+        return res
+
+    def _step(self, images, labels):
         key = self._key(images, labels)
         cap = self.graphs.get(key)
         last, self._last_key = getattr(self, "_last_key", None), key
@@ -165,6 +182,7 @@ class StepGraphs:
             if cap is None:
                 return None
         cap.last_used = self.replays
+        self._switch(True, images.device)
         return self._replay(cap, images, labels)
 
     def _throttle(self):

@@ -26,6 +26,21 @@ def _run(*args, **kw):
         torch.backends.cudnn.deterministic = det
 
 
+class _SyncTail:
+    def __init__(self, items, n, epoch):
+        self.items, self.n, self.epoch = items, n, epoch
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        for i, it in enumerate(self.items):
+            if i >= len(self.items) - self.n:
+                torch.cuda.synchronize()
+                print(f"    epoch {self.epoch}: everything before step {i} of {len(self.items)} has finished on the device", flush=True)
+            yield it
+
+
 def _same(a, b):
     """graph-served == eager, bit for bit: every per-step loss, the queue, student, EMA teacher, attention weights, the update"""
     assert np.array_equal(a["loss"], b["loss"]), np.abs(a["loss"] - b["loss"]).max()
@@ -37,7 +52,7 @@ def _same(a, b):
 
 
 def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16,
-              attn="self", mem="MoCo", data_on_device=False, validate=False):
+              attn="self", mem="MoCo", data_on_device=False, validate=False, print_freq=1000, sync_tail=0):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -53,7 +68,7 @@ def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, s
     with torch.no_grad():
         s_dim = ms.eval()(torch.randn(2, 3, size, size), is_feat=True)[0][-1].shape[1]
     opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
-                             cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=1000,
+                             cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=print_freq,
                              batch_size=B, rank=0, world_size=1, s_dim=s_dim, t_dim=s_dim, moma_prec=prec, queue_dtype=queue_dtype,
                              moma_fused=True, trace=[], overlap_teacher=overlap, graph_teacher=True, graph_student=graph_student,
                              amp=amp)
@@ -82,6 +97,8 @@ def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, s
     torch.manual_seed(99)                                              # the Shuffle-BN permutation stream (host generator)
     for ep in range(epochs):
         loader = data[ep * steps:(ep + 1) * steps] + ([data[-1]] if ep == epochs - 1 else [])
+        if sync_tail:           # (diagnostics: a device synchronisation + a progress line in front of each of the epoch's last steps)
+            loader = _SyncTail(loader, sync_tail, ep + 1)
         train_distill_moma(ep + 1, loader, mods, crits, trainer, contrast, optimizer, opt)
         if validate:            # as the CLI does between two epochs: every module in eval mode, the student forward without autocast
             from moma_amd.helper.loops_moma import validate_distill
@@ -189,6 +206,25 @@ def test_step_graphs_with_fp16_and_a_grad_scaler(scale0):
     assert np.isfinite(a["loss"]).all() and np.isfinite(b["loss"]).all()
     _same(a, b)
     assert all(a["student"][name] == 15 for name in a["student"] if "num_batches_tracked" in name)
+
+
+def test_an_eager_step_behind_replays_in_flight_finishes():
+    """Round 6: with the teacher side on its own stream and the batches already on the device (nothing in a step blocks the host, so
+    it runs up to three replayed steps ahead), the EAGER step of a ragged last batch issued behind replays still in flight never
+    finished -- the epoch's closing read-back waited for good (second run of a process, EfficientNet pair with bf16 autocast:
+    reproducible; not with one stream, not with a synchronisation in front of the switch).  StepGraphs now drains the device where
+    the loop switches between replayed and eager steps.  Runs in a child process under a watchdog (a regression would hang, not
+    fail): three consecutive graph-served runs must finish."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HANG="1", VAL="0", DEVDATA="1", ONLY="effiB0", MODE_LIMIT_S="90")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag_equivalences.py")], capture_output=True, text=True, timeout=600,
+                       cwd=root, env=env)
+    assert r.returncode == 0 and r.stdout.count("finished, last loss") == 3, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_step_graphs_follow_a_replaced_queue_and_the_optimizer():
