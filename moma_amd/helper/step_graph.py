@@ -144,8 +144,8 @@ class StepGraphs:
         never finished -- the process sat in the epoch's closing read-back for good (scripts/diag_equivalences.py, HANG=1: the
         second run of a process, EfficientNet pair, reproducible; not with one stream, not with a synchronisation in front of the
         step).  Cause inside the runtime not established; a switch happens a few times per epoch, the drain costs nothing there."""
-        if getattr(self, "_replayed_last", None) not in (None, replayed):
-            torch.cuda.synchronize(device)
+        if getattr(self, "_replayed_last", None) not in (None, replayed) and os.environ.get("MOMA_GRAPH_SWITCH_DRAIN", "1") == "1":
+            torch.cuda.synchronize(device)                 # (MOMA_GRAPH_SWITCH_DRAIN=0: the diagnostic that reproduces the hang)
         self._replayed_last = replayed
 
     def step(self, images, labels):
