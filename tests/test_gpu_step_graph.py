@@ -52,7 +52,7 @@ def _same(a, b):
 
 
 def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, steps=7, B=8, K=256, d=64, size=32, lr=0.02, scale0=2.0 ** 16,
-              attn="self", mem="MoCo", data_on_device=False, validate=False, print_freq=1000, sync_tail=0):
+              attn="self", mem="MoCo", data_on_device=False, validate=False, print_freq=1000, sync_tail=0, graph_teacher=True):
     from moma_amd.backbones import model_dict
     from moma_amd.MoMA.mem_moco import build_mem
     from moma_amd.MoMA.criterion_moco_att import CMO
@@ -70,7 +70,7 @@ def _run_impl(graph_student, model, overlap, prec, queue_dtype, amp, epochs=2, s
     opt = argparse.Namespace(distill="moma", head="mlp", feat_dim=d, attn=attn, mem=mem, nce_k=K, nce_t=0.15, alpha=0.99,
                              cls=1.0, div=1.0, beta=1.0, kd_T=4.0, gpu=0, multiprocessing_distributed=False, print_freq=print_freq,
                              batch_size=B, rank=0, world_size=1, s_dim=s_dim, t_dim=s_dim, moma_prec=prec, queue_dtype=queue_dtype,
-                             moma_fused=True, trace=[], overlap_teacher=overlap, graph_teacher=True, graph_student=graph_student,
+                             moma_fused=True, trace=[], overlap_teacher=overlap, graph_teacher=graph_teacher, graph_student=graph_student,
                              amp=amp)
     contrast = build_mem(opt)
     kd = CMO(opt)
