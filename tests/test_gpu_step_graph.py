@@ -157,6 +157,22 @@ def test_the_eager_loop_repeats_bit_for_bit(prec, queue_dtype):
     assert c["replays"] == 9 and a["index"] == b["index"] == c["index"]
 
 
+@pytest.mark.parametrize("model,amp,kw", [("resnet8", None, {}), ("effiB0", "bf16", dict(B=16, K=1024, d=128, size=64, lr=0.02))])
+def test_execution_modes_change_no_bit(model, amp, kw):
+    """Where the launches come from and which stream carries them must not change a single bit: the teacher side on its own stream
+    or on the main one, the step graph-served or eager, the teacher's forward graph-served or not, the batches copied from the host
+    or resident on the device (the host then runs ahead).  A difference would be a race or a dependence on issue order
+    (scripts/diag_equivalences.py runs the longer form of this check; in round 6 it found the hang of
+    test_an_eager_step_behind_replays_in_flight_finishes)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ref = _run(False, model, False, "bf16", "bf16", amp, **kw)                               # eager, one stream, host batches
+    for graph, overlap, dev, gt in ((False, True, False, True), (True, False, False, True), (True, True, True, True), (True, True, True, False)):
+        got = _run(graph, model, overlap, "bf16", "bf16", amp, data_on_device=dev, graph_teacher=gt, **kw)
+        _same(got, ref)
+        assert got["index"] == ref["index"] and got["next_perm"] == ref["next_perm"]
+
+
 @pytest.mark.parametrize("attn", ["self_mix", "self_nomix"])
 def test_step_graphs_serve_the_attention_in_shuffle_variants(attn):
     """--attn self_mix / self_nomix (learning/contrast_trainer.py:_shuffle_bn_attn, reference :135-187: the attention applied in
